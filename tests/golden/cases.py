@@ -1,0 +1,203 @@
+"""Case definitions shared by the golden generator (reference side) and the tests
+(oracle / HIP side): configs, masks and sub-sampling.  numpy only."""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+FMIN = float(np.finfo(np.float32).min)
+
+# (batch, seq) per module-level tag; 'wide' uses L=17 (not a tile multiple, as in the
+# reference tests' 17-token rows)
+MODULE_BL = {"micro": (2, 16), "wide": (2, 17)}
+
+
+@dataclass
+class TextCfg:
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    max_position_embeddings: int = 514
+    num_hidden_layers: int = 4
+    vocab_size: int = 50265
+    hidden_dropout_prob: float = 0.1
+    initializer_range: float = 0.02
+    intermediate_size: int = 3072
+    layer_norm_eps: float = 1e-05
+    hidden_act: str = "gelu"
+
+
+@dataclass
+class GqaCfg(TextCfg):
+    num_key_value_heads: int = 4
+
+
+@dataclass
+class VitCfg:
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    image_size: Tuple[int, int] = (224, 224)
+    patch_size: Tuple[int, int] = (16, 16)
+    num_channels: int = 3
+    num_hidden_layers: int = 4
+    hidden_dropout_prob: float = 0.1
+    initializer_range: float = 0.02
+    intermediate_size: int = 3072
+    layer_norm_eps: float = 1e-05
+    hidden_act: str = "gelu"
+
+
+def test_cfg() -> TextCfg:
+    """The Config of the reference's tests (tests/test_decoder.py:12-23)."""
+    return TextCfg()
+
+
+test_cfg.__test__ = False  # not a pytest test
+
+
+def micro_cfg() -> GqaCfg:
+    return GqaCfg(hidden_size=64, num_attention_heads=4, max_position_embeddings=64,
+                  num_hidden_layers=1, vocab_size=97, num_key_value_heads=2)
+
+
+def wide_cfg() -> GqaCfg:
+    return GqaCfg(num_hidden_layers=1, num_key_value_heads=4)
+
+
+def vit_cfg() -> VitCfg:
+    return VitCfg()
+
+
+def with_kv(cfg, attn_type: Optional[str]):
+    """Config for a vanilla / gqa model.  The reference's StaticCacheOne reads
+    config.num_key_value_heads even for vanilla attention (layers/kv_cache.py:275-282), so
+    vanilla configs must not carry the attribute."""
+    base = {k: getattr(cfg, k) for k in TextCfg.__dataclass_fields__ if hasattr(cfg, k)}
+    if attn_type == "gqa":
+        return GqaCfg(**base, num_key_value_heads=getattr(cfg, "num_key_value_heads", 4))
+    return TextCfg(**base)
+
+
+def one_layer(cfg, gqa: bool):
+    c = with_kv(cfg, "gqa" if gqa else None)
+    c.num_hidden_layers = 1
+    return c
+
+
+def keypad(batch: int, seq: int) -> np.ndarray:
+    """(B, L) int64 0/1 right-padding mask; row b keeps seq - (3*b + 2) % (seq//2) tokens, row 0 full."""
+    m = np.ones((batch, seq), dtype=np.int64)
+    for b in range(1, batch):
+        keep = seq - ((3 * b + 2) % max(seq // 2, 1)) - 1
+        m[b, keep:] = 0
+    return m
+
+
+def causal_additive(batch: int, seq: int, start_pos: int, keypad_full: Optional[np.ndarray]) -> np.ndarray:
+    """Dense (B,1,L,start+L) additive fp32 mask as DecoderModel builds it
+    (reference models/decoder.py:360-362, 376-419), restated in numpy."""
+    total = seq + start_pos
+    am = np.ones((batch, total), dtype=np.float32) if keypad_full is None else keypad_full.astype(np.float32)
+    i = np.arange(seq)[:, None]
+    j = np.arange(total)[None, :]
+    causal = (j <= i + start_pos).astype(np.float32)
+    ext = causal[None, None] * am[:, None, None, :]
+    return ((1.0 - ext) * FMIN).astype(np.float32)
+
+
+def reference_test_inputs():
+    """Token rows / masks hard-coded in the reference tests (tests/test_decoder.py:28-46)."""
+    ids = np.array([
+        [0, 2387, 766, 16, 181, 967, 46035, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+        [0, 12196, 16, 110, 766, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+        [0, 37111, 1137, 162, 110, 766, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]], dtype=np.int64)
+    am = np.array([
+        [1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+        [1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+        [1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]], dtype=np.int64)
+    return ids, am
+
+
+def sub(y):
+    """Sub-sample a (B, L, D) activation: every 8th position (offset 1) x every 4th feature."""
+    return y[:, 1::8, ::4]
+
+
+def sub2(g):
+    """Sub-sample a 2-D gradient: rows ::7, cols ::5."""
+    return g[::7, ::5]
+
+
+# ---------------------------------------------------------------------------
+# parameter name -> shape tables (reference state_dict layout)
+# ---------------------------------------------------------------------------
+
+
+def attn_shapes(cfg, kind: str):
+    """kind in {'vanilla','gqa','vision'}; names relative to the attention module."""
+    d = cfg.hidden_size
+    dh = d // cfg.num_attention_heads
+    s = {}
+    if kind == "vision":
+        s["qkv.weight"], s["qkv.bias"] = (3 * d, d), (3 * d,)
+    else:
+        kv = d if kind == "vanilla" else getattr(cfg, "num_key_value_heads", 4) * dh
+        s["query.weight"], s["query.bias"] = (d, d), (d,)
+        s["key.weight"], s["key.bias"] = (kv, d), (kv,)
+        s["value.weight"], s["value.bias"] = (kv, d), (kv,)
+    s.update(aso_shapes(cfg, "out."))
+    return s
+
+
+def aso_shapes(cfg, p=""):
+    d = cfg.hidden_size
+    return {p + "dense.weight": (d, d), p + "dense.bias": (d,),
+            p + "layernorm.weight": (d,), p + "layernorm.bias": (d,)}
+
+
+def ffn_shapes(cfg, p=""):
+    d = cfg.hidden_size
+    return {p + "intermediate.weight": (4 * d, d), p + "intermediate.bias": (4 * d,),
+            p + "layernorm.weight": (d,), p + "layernorm.bias": (d,),
+            p + "out.weight": (d, 4 * d), p + "out.bias": (d,)}
+
+
+def layer_shapes(cfg, kind: str, p=""):
+    s = {p + "attention." + k: v for k, v in attn_shapes(cfg, kind).items()}
+    s.update(ffn_shapes(cfg, p + "feed_forward."))
+    return s
+
+
+def lm_head_shapes(cfg, p="lm_head."):
+    d, v = cfg.hidden_size, cfg.vocab_size
+    return {p + "bias": (v,), p + "dense.weight": (d, d), p + "dense.bias": (d,),
+            p + "layer_norm.weight": (d,), p + "layer_norm.bias": (d,),
+            p + "decoder.weight": (v, d), p + "decoder.bias": (v,)}
+
+
+def text_model_shapes(cfg, pos: str, attn_type, head: bool, p=""):
+    d = cfg.hidden_size
+    s = {p + "word_embeddings.weight": (cfg.vocab_size, d)}
+    if pos == "absolute":
+        s[p + "position_embeddings.pos_embeddings.weight"] = (cfg.max_position_embeddings, d)
+    kind = "gqa" if attn_type == "gqa" else "vanilla"
+    for i in range(cfg.num_hidden_layers):
+        s.update(layer_shapes(cfg, kind, f"{p}all_layer.{i}."))
+    if head:
+        s.update(lm_head_shapes(cfg, p + "lm_head."))
+    return s
+
+
+def vit_shapes(cfg, p=""):
+    d = cfg.hidden_size
+    ph, pw = cfg.patch_size
+    n = (cfg.image_size[0] // ph) * (cfg.image_size[1] // pw)
+    pd = cfg.num_channels * ph * pw
+    s = {p + "cls_token": (1, 1, pd), p + "position_embeddings.pos_embeddings": (1, n + 1, pd)}
+    for i in range(cfg.num_hidden_layers):
+        s.update(layer_shapes(cfg, "vision", f"{p}all_layer.{i}."))
+    s[p + "pixel_seq.weight"] = (d, cfg.num_channels, ph, pw)
+    s[p + "pixel_seq.bias"] = (d,)
+    return s

@@ -1,0 +1,242 @@
+"""Generate golden vectors by running the REAL reference (Ajax0564/VyomAI) on CPU.
+
+Runs only in the build container, where the reference is mounted read-only:
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference:/root/repo \
+        python tests/golden/make_golden.py
+
+It imports the reference package, fills its modules with the deterministic recipe
+(`vyomai_amd.recipe`), feeds recipe-derived inputs and stores the *outputs* as small
+``.npz`` fixtures next to this file.  Nothing of the reference (source, bytecode) is
+written anywhere; fixtures are data only.  The tests regenerate the inputs from the
+same recipe, so only outputs (sub-sampled where large) are stored.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import VyomAI  # noqa: E402  (the reference)
+from VyomAI.layers import attention as ref_attn  # noqa: E402
+from VyomAI.layers import ffn as ref_ffn  # noqa: E402
+from VyomAI.layers import positional_embeddings as ref_pos  # noqa: E402
+from VyomAI.layers.kv_cache import DynamicCache, StaticCache, StaticCacheOne, DynamicCacheOne  # noqa: E402
+from VyomAI.models import decoder as ref_dec  # noqa: E402
+from VyomAI.models.encoder import EncoderModel  # noqa: E402
+from VyomAI.models.vision_encoder import Vit  # noqa: E402
+from VyomAI.models.multimodel import VisionLanguageModel  # noqa: E402
+from VyomAI.generation_utils import generate_multimodel, generate  # noqa: E402
+
+from vyomai_amd import recipe  # noqa: E402
+from tests.golden import cases  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def T(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name: str, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().float().numpy() if v.is_floating_point() else v.detach().numpy()
+        out[k] = np.ascontiguousarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB  keys={len(out)}")
+
+
+def filled(module, prefix=""):
+    recipe.load_recipe_(module) if not prefix else None
+    if prefix:
+        sd = module.state_dict()
+        for n, t in sd.items():
+            if t.is_floating_point():
+                t.copy_(T(recipe.param_value(prefix + n, tuple(t.shape))))
+    return module.eval()
+
+
+# ---------------------------------------------------------------------------
+# A. module level
+# ---------------------------------------------------------------------------
+
+
+def module_level():
+    out = {}
+    for tag, cfg in (("micro", cases.micro_cfg()), ("wide", cases.wide_cfg())):
+        B, L = cases.MODULE_BL[tag]
+        d, h = cfg.hidden_size, cfg.num_attention_heads
+        dh = d // h
+        x = T(recipe.uniform(f"{tag}.x", (B, L, d)))
+        res = T(recipe.uniform(f"{tag}.res", (B, L, d)))
+        keypad = T(cases.keypad(B, L))
+        add_mask = (1.0 - keypad[:, None, None, :].float()) * torch.finfo(torch.float32).min
+        freqs = ref_pos.RotaryEmbedding(cfg)(cfg.max_position_embeddings)[:, :L]
+
+        # rope alone
+        q = T(recipe.uniform(f"{tag}.q", (B, h, L, dh)))
+        k = T(recipe.uniform(f"{tag}.k", (B, h, L, dh)))
+        qe, ke = ref_pos.apply_rotary_pos_emb(q, k, freqs)
+        out[f"{tag}.rope.q"], out[f"{tag}.rope.k"] = qe, ke
+        out[f"{tag}.rope.angles"] = freqs
+
+        m = filled(ref_ffn.FeedForward(cfg), f"{tag}.ffn.")
+        out[f"{tag}.ffn"] = m(x, res)
+        m = filled(ref_attn.AttentionSelfOutput(cfg), f"{tag}.aso.")
+        out[f"{tag}.aso"] = m(x, res)
+
+        for name, cls in (("enc", ref_attn.EncoderAttention), ("encgqa", ref_attn.EncoderAttentionGqa),
+                          ("vis", ref_attn.VisionAttention)):
+            m = filled(cls(cfg, 0), f"{tag}.{name}.")
+            out[f"{tag}.{name}.keypad"] = m(x, add_mask)
+            out[f"{tag}.{name}.nomask"] = m(x, None)
+            out[f"{tag}.{name}.keypad.rope"] = m(x, add_mask, freqs)
+
+        # decoder attention with whole-model caches: prefill L then 3 single-token steps
+        for name, cls, gqa in (("dec", ref_dec.DecoderAttention, False), ("decgqa", ref_dec.DecoderAttentionGqa, True)):
+            for cname in ("static", "dynamic"):
+                m = filled(cls(cfg, 0), f"{tag}.{name}.")
+                c1 = cases.one_layer(cfg, gqa)
+                cache = (StaticCacheOne(c1, max_cache_len=L + 3, batch_size=B) if cname == "static"
+                         else DynamicCacheOne(c1))
+                full_freqs = ref_pos.RotaryEmbedding(cfg)(cfg.max_position_embeddings)
+                causal = cases.causal_additive(B, L, 0, None)
+                y, _ = m(x, T(causal), full_freqs[:, :L], True, cache, 0)
+                out[f"{tag}.{name}.{cname}.prefill"] = y
+                for s in range(3):
+                    xs = T(recipe.uniform(f"{tag}.xstep{s}", (B, 1, d)))
+                    y, _ = m(xs, None, full_freqs[:, L + s:L + s + 1], True, cache, L + s)
+                    out[f"{tag}.{name}.{cname}.step{s}"] = y
+                if cname == "static":
+                    out[f"{tag}.{name}.static.kcache"] = cache.key_cache[0][:, :, :L + 3].clone()
+                    out[f"{tag}.{name}.static.vcache"] = cache.value_cache[0][:, :, :L + 3].clone()
+            # causal + key padding + start_pos>0 chunked prefill (second chunk of 5 tokens)
+            m = filled(cls(cfg, 0), f"{tag}.{name}.")
+            c1 = cases.one_layer(cfg, gqa)
+            cache = DynamicCacheOne(c1)
+            full_freqs = ref_pos.RotaryEmbedding(cfg)(cfg.max_position_embeddings)
+            kp = cases.keypad(B, L)
+            y0, _ = m(x[:, :L - 5], T(cases.causal_additive(B, L - 5, 0, kp[:, :L - 5])), full_freqs[:, :L - 5], True, cache, 0)
+            y1, _ = m(x[:, L - 5:], T(cases.causal_additive(B, 5, L - 5, kp)), full_freqs[:, L - 5:L], True, cache, L - 5)
+            out[f"{tag}.{name}.chunk0"] = y0
+            out[f"{tag}.{name}.chunk1"] = y1
+    save("modules", **out)
+
+
+# ---------------------------------------------------------------------------
+# B/C. model level + token exact
+# ---------------------------------------------------------------------------
+
+
+def model_level():
+    out = {}
+    # config 1: EncoderModel(EncoderConfig(), 'absolute'), B=4, L=128
+    cfg = VyomAI.EncoderConfig()
+    ids = T(recipe.token_ids("enc.ids", (4, 128), 3, cfg.vocab_size))
+    am = T(cases.keypad(4, 128)).float()
+    for pos, at in (("absolute", None), ("rope", None), ("sinusoidal", "gqa"), ("rope", "gqa")):
+        c = cases.with_kv(cfg, at)
+        m = filled(EncoderModel(c, pos, at))
+        y = m(ids, am).logits
+        out[f"encoder.{pos}.{at}.full_nopad"] = cases.sub(m(ids, None).logits)
+        out[f"encoder.{pos}.{at}.pad"] = cases.sub(y)
+        out[f"encoder.{pos}.{at}.pad.sum"] = np.array([y.double().sum().item(), y.double().abs().sum().item()])
+
+    # decoder, the reference tests' own inputs (tests/test_decoder.py:28-46)
+    ids3, am3 = cases.reference_test_inputs()
+    ids3, am3 = T(ids3), T(am3)
+    for pos in ("absolute", "sinusoidal", "rope"):
+        for at in (None, "gqa"):
+            c = cases.with_kv(cases.test_cfg(), at)
+            m = filled(ref_dec.DecoderModel(c, pos, at))
+            o = m(ids3, am3)
+            out[f"decoder.{pos}.{at}.hidden"] = o.hidden_state
+            out[f"decoder.{pos}.{at}.logits"] = o.logits[:, :, ::97]
+            # token-exact greedy generation, three cache modes, prompt of the reference test
+            p = torch.tensor([[9226, 16, 5, 1296]], dtype=torch.long)
+            a = torch.ones(1, 4, dtype=torch.long)
+            out[f"decoder.{pos}.{at}.gen.nocache"] = m.generate(p, a, use_cache=False)
+            out[f"decoder.{pos}.{at}.gen.dynamic"] = m.generate(p, a, use_cache=True)
+            out[f"decoder.{pos}.{at}.gen.static"] = m.generate(p, a, use_cache=True, use_static_cache=True)
+            # batch of 3 equal-length prompts, 6 new tokens
+            pb = T(recipe.token_ids("dec.prompt3", (3, 9), 3, c.vocab_size))
+            ab = torch.ones(3, 9, dtype=torch.long)
+            out[f"decoder.{pos}.{at}.gen3.static"] = m.generate(pb, ab, max_len=6, use_cache=True, use_static_cache=True)
+            out[f"decoder.{pos}.{at}.gen3.nocache"] = m.generate(pb, ab, max_len=6, use_cache=False)
+            if pos == "rope" and at is None:
+                # bf16-on-CPU run of the same model: the reference's own bf16 gap
+                mb = filled(ref_dec.DecoderModel(c, pos, at)).to(torch.bfloat16)
+                mb.emb_freq = mb.emb_freq  # plain tensor attr stays fp32 (decoder.py:301)
+                ob = mb(ids3, am3)
+                out["decoder.rope.None.hidden.bf16"] = ob.hidden_state.float()
+                # generation_utils.generate (no cache), 4 tokens
+                out["decoder.rope.None.utilsgen"] = generate(m, p, max_new_tokens=4)
+    save("models_text", **out)
+
+    out = {}
+    vcfg = cases.vit_cfg()
+    img = T(recipe.uniform("vit.img", (2, 3, 224, 224), 0.5, 0.5))
+    vit = filled(Vit(vcfg))
+    y = vit(img.clone()).logits
+    out["vit.out"] = cases.sub(y)
+    out["vit.cls"] = y[:, 0, :]
+    for pos, at in (("absolute", None), ("rope", "gqa"), ("rope", None)):
+        c = cases.with_kv(cases.test_cfg(), at)
+        vlm = VisionLanguageModel(c, Vit(vcfg), pos, at)
+        filled(vlm)
+        o = vlm(pixel_values=img.clone(), decoder_input_ids=ids3[:2], decoder_attention_mask=am3[:2])
+        out[f"vlm.{pos}.{at}.logits"] = o.logits[:, :, ::97]
+        enc = vlm.get_encoder_output(pixel_values=img[:1].clone())
+        out[f"vlm.{pos}.{at}.enc"] = enc
+        idx = torch.tensor([[0]])
+        out[f"vlm.{pos}.{at}.gen.nocache"] = generate_multimodel(vlm, enc, None, idx, max_new_tokens=8)
+        vlm._clean_cache(); vlm._setup_cache(c)
+        out[f"vlm.{pos}.{at}.gen.static"] = generate_multimodel(vlm, enc, None, idx, max_new_tokens=8, use_cache=True)
+        vlm._clean_cache(); vlm._setup_cache(c, cls=DynamicCache)
+        out[f"vlm.{pos}.{at}.gen.dynamic"] = generate_multimodel(vlm, enc, None, idx, max_new_tokens=8, use_cache=True)
+    save("models_vision", **out)
+
+
+# ---------------------------------------------------------------------------
+# D. gradients of a one-layer loss through the reference
+# ---------------------------------------------------------------------------
+
+
+def gradients():
+    out = {}
+    torch.set_grad_enabled(True)
+    for tag, cfg in (("micro", cases.micro_cfg()), ("wide", cases.wide_cfg())):
+        B, L = cases.MODULE_BL[tag]
+        d = cfg.hidden_size
+        for at in (None, "gqa"):
+            layer = filled(ref_dec.DecoderLayer(cfg, 0, at), f"{tag}.layer.{at}.")
+            x = T(recipe.uniform(f"{tag}.x", (B, L, d))).requires_grad_(True)
+            g = T(recipe.uniform(f"{tag}.gout", (B, L, d)))
+            freqs = ref_pos.RotaryEmbedding(cfg)(cfg.max_position_embeddings)[:, :L]
+            mask = T(cases.causal_additive(B, L, 0, cases.keypad(B, L)))
+            y, _ = layer(x, mask, freqs)
+            (y * g).sum().backward()
+            out[f"{tag}.{at}.y"] = y
+            out[f"{tag}.{at}.dx"] = x.grad
+            for n, p in layer.named_parameters():
+                gr = p.grad
+                out[f"{tag}.{at}.d.{n}"] = gr if gr.numel() <= 4096 else cases.sub2(gr)
+    torch.set_grad_enabled(False)
+    save("grads", **out)
+
+
+if __name__ == "__main__":
+    module_level()
+    model_level()
+    gradients()
