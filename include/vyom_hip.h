@@ -1,0 +1,191 @@
+/*
+ * vyom_hip.h -- C ABI of libvyom_hip.so, the MI355X (gfx950 / CDNA4) kernel library
+ * behind vyomai_amd's mirror of the VyomAI layer API.
+ *
+ * The reference (Ajax0564/VyomAI) has no FFI: its hot path is the Python class API of
+ * VyomAI/layers consumed by VyomAI/models.  Each entry point
+ * below replaces the torch ops that one reference call site issues; the citation after
+ * "replaces:" is path:line in the reference checkout.
+ *
+ * Conventions (every function):
+ *   - plain device pointers + explicit sizes/strides (in ELEMENTS unless noted), no torch types;
+ *   - `dtype`: VY_F32 or VY_BF16 -- the storage type of activations/weights; accumulation,
+ *     softmax and norm statistics are always fp32;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised;
+ *   - no device allocation inside; callers pass workspaces;
+ *   - returns 0 on success, a negative vy_status otherwise; vy_last_error() describes it.
+ */
+#ifndef VYOM_HIP_H
+#define VYOM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { VY_F32 = 0, VY_BF16 = 1 } vy_dtype;
+
+typedef enum {
+  VY_OK = 0,
+  VY_ERR_ARG = -1,       /* bad shape / alignment / null pointer */
+  VY_ERR_UNSUPPORTED = -2,
+  VY_ERR_LAUNCH = -3     /* hipGetLastError() after the launch */
+} vy_status;
+
+typedef enum { VY_ACT_NONE = 0, VY_ACT_GELU_ERF = 1, VY_ACT_GELU_TANH = 2 } vy_act;
+
+/* attention mask descriptor bits (vy_attn_fwd / vy_attn_bwd) */
+enum {
+  VY_MASK_NONE = 0,
+  VY_MASK_CAUSAL = 1,   /* key j visible to query i iff j <= i + start_pos              */
+  VY_MASK_KEYPAD = 2,   /* uint8 keep[B][S]; 0 = masked with finfo.min like the reference */
+  VY_MASK_ADDITIVE = 4  /* generic fp32 additive mask (B,1,Lm,S), Lm in {1, L}            */
+};
+
+const char* vy_last_error(void);
+int vy_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * vy_linear_fwd:  Y[M,N] = act(X[M,K] . W[N,K]^T + bias[N]) + residual[M,N]
+ * replaces: nn.Linear call sites -- AttentionSelfOutput.dense + residual add
+ *   (VyomAI/layers/attention.py:69-71), FeedForward.intermediate + GELU and FeedForward.out +
+ *   residual (VyomAI/layers/ffn.py:35-39), LMHead.dense/decoder (VyomAI/models/decoder.py:267-275).
+ * `pre_out` (nullable, [M,ldy]) receives X.W^T+bias before the activation (saved for backward).
+ * bias/residual/pre_out may be NULL.  K % 8 == 0 (bf16) / K % 4 == 0 (f32); rows 16-byte aligned.
+ * ------------------------------------------------------------------------------------------ */
+int vy_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                  const void* residual, int64_t ldr, void* y, int64_t ldy, void* pre_out,
+                  int64_t M, int64_t N, int64_t K, int act, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vy_qkv_rope_fwd: fused Q/K/V projection + bias + rotary embedding + head split.
+ * replaces: self.query/key/value (or self.qkv + chunk), rearrange 'b l (h d) -> b h l d',
+ *   apply_rotary_pos_emb and the KV-cache slice write
+ *   (VyomAI/layers/attention.py:114-126, 607-617; VyomAI/models/decoder.py:91-105;
+ *    VyomAI/layers/positional_embeddings.py:155-182; VyomAI/layers/kv_cache.py:355-356).
+ * w: packed [(h + 2*hk)*dh, K] rows = [Wq; Wk; Wv]; bias likewise or NULL.
+ * cos/sin: fp32 tables [>= pos0+L][dh/2] (angles' cos/sin, half width) or NULL for no RoPE;
+ *          row (pos0 + l) is used for token l.
+ * q/k/v outputs are (B, heads, *, dh) with element strides {batch, head, token}; writing K/V
+ * straight into a static cache is done by pointing k/v at cache[:, :, start_pos] with the
+ * cache's strides.
+ * ------------------------------------------------------------------------------------------ */
+int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                    const float* cos_tab, const float* sin_tab, int64_t pos0,
+                    void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                    void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                    void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                    int64_t B, int64_t L, int64_t K, int h, int hk, int dh, int dtype,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vy_attn_fwd: softmax(Q K^T / sqrt(dh) + mask) V, flash style, heads merged on output.
+ * replaces: repeat_kv + F.scaled_dot_product_attention + rearrange 'b h l d -> b l (h d)'
+ *   (VyomAI/layers/attention.py:8-19, 128-132, 205-213, 283-287, 368-377, 619-623;
+ *    VyomAI/models/decoder.py:107-111, 190-199).
+ * q (B,h,L,dh), k/v (B,hk,S,dh) with element strides {batch, head, token}; kv head of query
+ * head i is i / (h/hk).  out is (B, L, h*dh) with strides {o_sb, o_sl}.
+ * mask_kind: OR of VY_MASK_*; keypad uint8 [B][S] (stride kp_sb); additive fp32 with strides
+ * {am_sb, am_sl} (am_sl = 0 broadcasts one row).  Masked scores take finfo(fp32).min exactly as
+ * the reference's (1-mask)*finfo.min does, so a fully masked row averages V.
+ * lse (nullable) fp32 [B,h,L]: natural-log sum-exp of the scaled, masked scores (for backward).
+ * ------------------------------------------------------------------------------------------ */
+int vy_attn_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                const void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                void* out, int64_t o_sb, int64_t o_sl, float* lse,
+                int mask_kind, int64_t start_pos, const uint8_t* keypad, int64_t kp_sb,
+                const float* addmask, int64_t am_sb, int64_t am_sl,
+                int64_t B, int h, int hk, int64_t L, int64_t S, int dh, float scale, int dtype,
+                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vy_attn_decode: one query token per sequence against a KV cache (L == 1, no mask).
+ * replaces: the L==1 branch of DecoderAttention*.forward (mask=None, VyomAI/models/decoder.py:
+ *   355-356, 105-111) reading StaticCacheOne/DynamicCacheOne prefixes (VyomAI/layers/kv_cache.py:
+ *   229-236, 358-361).  q (B,h,1,dh) strides {q_sb,q_sh}; k/v cache strides {batch, head, token};
+ *   S = start_pos + 1 keys are attended.  out (B,1,h*dh) row stride o_sb.
+ * ------------------------------------------------------------------------------------------ */
+int vy_attn_decode(const void* q, int64_t q_sb, int64_t q_sh,
+                   const void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                   const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                   void* out, int64_t o_sb, int64_t B, int h, int hk, int64_t S, int dh,
+                   float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vy_layernorm_fwd: y = (x - mean) * rstd * gamma + beta over the last dim (biased variance).
+ * replaces: nn.LayerNorm in AttentionSelfOutput / FeedForward / LMHead
+ *   (VyomAI/layers/attention.py:71, VyomAI/layers/ffn.py:39, VyomAI/models/decoder.py:270).
+ * mean/rstd (nullable) fp32 [M] are saved for backward.
+ * ------------------------------------------------------------------------------------------ */
+int vy_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y,
+                     int64_t ldy, float* mean, float* rstd, int64_t M, int64_t N, float eps,
+                     int dtype, void* stream);
+
+/* vy_rope_fwd: in-place rotary embedding on a (B,heads,L,dh) tensor (strides as above);
+ * used when the fused epilogue does not apply.  `inverse` != 0 applies the transpose rotation
+ * (the backward of RoPE).  replaces: VyomAI/layers/positional_embeddings.py:155-182. */
+int vy_rope_fwd(void* x, int64_t sb, int64_t sh, int64_t sl, const float* cos_tab,
+                const float* sin_tab, int64_t pos0, int64_t B, int heads, int64_t L, int dh,
+                int inverse, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward / training entry points (bf16 storage, fp32 accumulation).
+ * They mirror what autograd derives for the reference modules; the fusion groups follow the
+ * author's own fused notebook (Examples/vyom-ai-decoder-fused.ipynb cells 2-7, 11).
+ * ------------------------------------------------------------------------------------------ */
+
+/* dX[M,K] = dY[M,N] . W[N,K]  (+ add_to[M,K]); optional GELU backward: when `pre` is given the
+ * result is multiplied by gelu'(pre[M,K]) (pre = saved pre-activation of the consumer of dX).
+ * wt is W transposed, i.e. stored [K,N] row-major (the trainer keeps both copies). */
+int vy_linear_dgrad(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const void* pre,
+                    int64_t ldpre, int act, const void* add_to, int64_t ldadd, void* dx,
+                    int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+
+/* dW[N,K] (fp32, accumulate when beta != 0) = dY[M,N]^T . X[M,K];  db[N] (fp32) = colsum(dY). */
+int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
+                    int64_t lddw, float* db, float beta, int64_t M, int64_t N, int64_t K,
+                    int dtype, void* stream);
+
+/* LayerNorm backward: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;
+ * dgamma/dbeta fp32 [N] accumulated (beta) from per-block partials in `ws`
+ * (ws: fp32, at least 2 * ws_rows * N elements; ws_rows = vy_layernorm_bwd_ws_rows(M)). */
+int64_t vy_layernorm_bwd_ws_rows(int64_t M);
+int vy_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
+                     const float* mean, const float* rstd, void* dx, int64_t lddx, float* dgamma,
+                     float* dbeta, float beta, float* ws, int64_t M, int64_t N, int dtype,
+                     void* stream);
+
+/* Flash attention backward.  dO/O are (B,L,h*dh) (strides {sb,sl}); dq/dk/dv use q/k/v layouts.
+ * delta_ws: fp32 [B,h,L] scratch.  dk/dv are (B,hk,S,dh): the n_rep query heads of one kv head
+ * are summed in-kernel.  Same mask descriptor as the forward. */
+int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl,
+                const void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl,
+                const void* out, const void* dout, int64_t o_sb, int64_t o_sl, const float* lse,
+                float* delta_ws,
+                void* dq, int64_t dq_sb, int64_t dq_sh, int64_t dq_sl,
+                void* dk, int64_t dk_sb, int64_t dk_sh, int64_t dk_sl,
+                void* dv, int64_t dv_sb, int64_t dv_sh, int64_t dv_sl,
+                int mask_kind, int64_t start_pos, const uint8_t* keypad, int64_t kp_sb,
+                int64_t B, int h, int hk, int64_t L, int64_t S, int dh, float scale, int dtype,
+                void* stream);
+
+/* Fused AdamW over a flat fp32 parameter arena; also refreshes the bf16 working copy.
+ * p, m, v fp32 [n]; g fp32 [n]; p_bf16 (nullable) bf16 [n].  Matches torch.optim.AdamW. */
+int vy_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                  float grad_scale, void* stream);
+
+/* out[c, r] = in[r, c] for a [R,C] matrix (bf16 or f32): keeps W^T copies for dgrad. */
+int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t R, int64_t C,
+                 int dtype, void* stream);
+
+/* y = x converted between fp32 and bf16 (n elements). src_dtype -> dst_dtype. */
+int vy_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VYOM_HIP_H */

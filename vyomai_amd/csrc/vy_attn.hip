@@ -1,0 +1,465 @@
+// Scaled-dot-product attention forward for the VyomAI hot path.
+//
+// attn_fwd_mfma_kernel (bf16, dh in {64,128}): flash-style, one workgroup = 4 waves = 128 query
+// rows of one (batch, head); K/V tiles of 64 keys are staged by LDS-DMA (double buffered).
+//   * "swapped" QK^T: S^T = K.Q^T (A operand = K rows read with ds_read_b128 from an XOR-swizzled
+//     [key][d] image, B operand = Q kept in registers), so each lane owns ONE query row and its
+//     softmax statistics; the row max/sum need one cross-half exchange (lane ^ 32) only;
+//   * P never leaves registers: the S^T accumulator is, after exp2 and a bf16 pack, exactly the
+//     B operand of O^T = V^T.P^T (k order permuted identically on both operands);
+//   * V^T fragments come from the row-major [key][d] V image through ds_read_b64_tr_b16 (the
+//     gfx950 transposing LDS read); the image is swizzled in 64-byte units so the four rows of a
+//     transposed read hit distinct banks;
+//   * GQA: kv head = q head / (h/hk) -- repeat_kv is never materialised;
+//   * masks are descriptors, not tensors: causal offset, key-padding bytes, or a generic additive
+//     fp32 mask.  Masked scores take -FLT_MAX exactly like the reference's additive
+//     (1-mask)*finfo.min (the score is absorbed), so a fully masked row averages V over all keys.
+//
+// attn_rowwise_kernel (f32 / any dh, and the L==1 decode path): one workgroup per query row, a
+// single online-softmax pass over K and V with 16-byte coalesced loads, no LDS score buffer.
+//
+// Reference: F.scaled_dot_product_attention call sites, VyomAI/layers/attention.py:128,209,283,
+// 373,619 and VyomAI/models/decoder.py:107,195.
+#include "vy_common.h"
+#include <float.h>
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnParams {
+  const void* q; int64_t q_sb, q_sh, q_sl;
+  const void* k; int64_t k_sb, k_sh, k_sl;
+  const void* v; int64_t v_sb, v_sh, v_sl;
+  void* out; int64_t o_sb, o_sl;
+  float* lse;
+  int mask_kind; int start_pos;
+  const uint8_t* keypad; int64_t kp_sb;
+  const float* addmask; int64_t am_sb, am_sl;
+  int B, h, hk, L, S;
+  float scale;
+};
+
+// ------------------------------------------------------------------------------------------
+// MFMA flash forward (bf16)
+// ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
+  constexpr int RB = DH * 2;            // bytes per K/V row
+  constexpr int TILE = 64 * RB;         // bytes per 64-key tile
+  constexpr int NP = TILE / 1024 / 4;   // 1-KiB LDS-DMA pieces per wave per tile
+  constexpr int KS = DH / 16;           // k-steps of the QK^T contraction
+  constexpr int ND = DH / 32;           // 32-wide d blocks of O^T
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // K0 K1 V0 V1
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (p.L + 127) / 128;
+  const int qb = nqb - 1 - (int)blockIdx.x;  // heaviest (most keys under a causal mask) first
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int kvh = head / (p.h / p.hk);
+  const int q0 = qb * 128;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int qi = q0 + wave * 32 + fr;  // this lane's query row
+  const int qrow = qi < p.L ? qi : p.L - 1;
+
+  const bf16* Q = (const bf16*)p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qrow * p.q_sl;
+  const bf16* Kb = (const bf16*)p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
+  const bf16* Vb = (const bf16*)p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + ks * 16 + fh * 8);
+
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const bool hasadd = p.mask_kind & VY_MASK_ADDITIVE;
+  const uint8_t* kp = haskp ? p.keypad + (int64_t)b * p.kp_sb : nullptr;
+  const float* am = hasadd ? p.addmask + (int64_t)b * p.am_sb + (int64_t)qrow * p.am_sl : nullptr;
+
+  // LDS-DMA source geometry: piece pc covers LDS bytes [pc*1024, +1024); lane byte P
+  int ld_row[NP], ld_koff[NP], ld_voff[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    const int P = (wave * NP + t) * 1024 + lane * 16;
+    const int row = P / RB, off = P % RB;
+    const int ksw = (RB == 128) ? ((row >> 1) & 7) : (row & 15);
+    const int vsw = (RB == 128) ? (((row >> 1) & 1) << 6) : ((row & 3) << 6);
+    ld_row[t] = row;
+    ld_koff[t] = ((((off >> 4) ^ ksw) << 4)) >> 1;  // element offset inside the row
+    ld_voff[t] = (off ^ vsw) >> 1;
+  }
+  auto stage = [&](int tile, int buf) {
+    const int k0 = tile * 64;
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      int kr = k0 + ld_row[t];
+      kr = kr < p.S ? kr : p.S - 1;
+      const bf16* ks = Kb + (int64_t)kr * p.k_sl + ld_koff[t];
+      const bf16* vs = Vb + (int64_t)kr * p.v_sl + ld_voff[t];
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)ks,
+                                       (VY_LDS void*)(smem + buf * TILE + (wave * NP + t) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)vs,
+                                       (VY_LDS void*)(smem + (2 + buf) * TILE + (wave * NP + t) * 1024), 16, 0, 0);
+    }
+  };
+
+  // read-side lane constants
+  const int k_sw = (RB == 128) ? ((fr >> 1) & 7) : (fr & 15);
+  const int li = lane & 15, g16 = (lane >> 4) & 1;
+  const int v_sw = (RB == 128) ? (((li >> 3) & 1) << 6) : (((li >> 2) & 3) << 6);
+  const int v_lane_row = 4 * fh + (li >> 2);            // + 32kb + 16s + 8u
+  const int v_lane_off = 32 * g16 + 8 * (li & 3);       // + 64n, then ^ v_sw
+
+  f32x16 o[ND];
+#pragma unroll
+  for (int n = 0; n < ND; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = p.scale * LOG2E;
+
+  // tile range.  Pure causal: keys beyond the diagonal of the block's last row are never
+  // visible -> skipped.  With a key-padding mask a row can be fully masked; the reference then
+  // averages V over ALL keys, so the loop is extended to S when that happens (see below).
+  const int nt_all = (p.S + 63) / 64;
+  int nt = nt_all;
+  if (causal) {
+    const int kv_end = min(p.S, p.start_pos + q0 + 128);
+    nt = (kv_end + 63) / 64;
+    if (nt < 1) nt = 1;
+  }
+  const int wave_first = q0 + wave * 32, wave_last = wave_first + 31;
+
+  auto compute = [&](int tile, int buf) {
+    const int k0 = tile * 64;
+    // wave-uniform skip of tiles wholly above this wave's diagonal (pure causal only)
+    if (causal && !haskp && !hasadd && k0 > p.start_pos + wave_last) return;
+    const char* kb_ = smem + buf * TILE;
+    const char* vb_ = smem + (2 + buf) * TILE;
+    f32x16 st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ k_sw) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+      }
+    }
+    const bool need_mask = haskp || hasadd || (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first);
+    float tmax = -INFINITY;
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kj = k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          float t = st[kb][r] * c;
+          if (kj < p.S) {
+            if (hasadd) t = fmaxf(t + am[kj] * LOG2E, -FLT_MAX);
+            if (causal && kj > qi + p.start_pos) t = -FLT_MAX;
+            if (haskp && !kp[kj]) t = -FLT_MAX;
+          } else {
+            t = -INFINITY;  // beyond the sequence: contributes nothing, ever
+          }
+          st[kb][r] = t;
+          tmax = fmaxf(tmax, t);
+        }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          st[kb][r] *= c;
+          tmax = fmaxf(tmax, st[kb][r]);
+        }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);  // finite: every tile holds >= 1 in-range key
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp2f(st[kb][r] - m_new);
+        st[kb][r] = e;
+        rs += e;
+      }
+    l_run = l_run * alpha + rs;  // per-half partial; halves are summed at the end
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+    // P fragments: registers 8s..8s+7 of block kb <-> keys 32kb+16s+8(j>>2)+4h+(j&3)
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[kb][s][j] = (bf16)st[kb][8 * s + j];
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int row = 32 * kb + 16 * s + v_lane_row;
+          const int off = (64 * n + v_lane_off) ^ v_sw;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(vb_ + row * RB + off));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(vb_ + (row + 8) * RB + off));
+          union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+          u.s.a = lo; u.s.b = hi;
+          o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pf[kb][s], o[n], 0, 0, 0);
+        }
+  };
+
+  // single tile loop (one inlined call site of compute(): the accumulators stay in registers).
+  // With a key-padding mask a row whose visible keys are all padding has m == -FLT_MAX; the
+  // reference's softmax over [finfo.min, ...] is then uniform over EVERY key, so the loop is
+  // extended over the causally skipped tiles when any row of the block is in that state.
+  int t = 0, t_end = nt;
+  stage(0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  while (true) {
+    for (; t < t_end; ++t) {
+      if (t + 1 < t_end) stage(t + 1, (t + 1) & 1);
+      compute(t, t & 1);
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+    }
+    if (t_end < nt_all && haskp && __syncthreads_or(m_run == -FLT_MAX && qi < p.L)) {
+      t_end = nt_all;
+      stage(t, t & 1);
+      __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();
+      continue;
+    }
+    break;
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (qi < p.L) {
+    bf16* O = (bf16*)p.out + (int64_t)b * p.o_sb + (int64_t)qi * p.o_sl + head * DH;
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (bf16)(o[n][4 * rg + e] * inv);
+        *reinterpret_cast<bf16x4*>(O + 32 * n + 8 * rg + 4 * fh) = w;
+      }
+    if (p.lse && fh == 0)
+      p.lse[((int64_t)b * p.h + head) * p.L + qi] = (m_run + log2f(l_tot)) * LN2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// row-wise kernel: f32 parity path, unusual head dims, and decode (L == 1)
+// one workgroup (4 waves) per (b, head, query row).  CPR lanes share one key row (16 B each).
+// ------------------------------------------------------------------------------------------
+template <typename T> struct RowVec;
+template <> struct RowVec<bf16> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void load(const bf16* p, float* v) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+};
+template <> struct RowVec<float> {
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ void load(const float* p, float* v) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  }
+};
+
+template <typename T, int CPR>  // CPR = dh / VEC lanes per key row, power of two <= 64
+__global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnParams p, int dh) {
+  constexpr int VEC = RowVec<T>::VEC;
+  constexpr int KPP = 64 / CPR;  // keys per wave pass
+  __shared__ float red_m[4 * KPP], red_l[4 * KPP];
+  __shared__ float red_o[4 * 64 * VEC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int kvh = head / (p.h / p.hk);
+  const int grp = lane / CPR, ch = lane % CPR;
+  const T* Q = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qi * p.q_sl;
+  const T* Kb = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
+  const T* Vb = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+  float qv[VEC];
+  RowVec<T>::load(Q + ch * VEC, qv);
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const bool hasadd = p.mask_kind & VY_MASK_ADDITIVE;
+  const uint8_t* kp = haskp ? p.keypad + (int64_t)b * p.kp_sb : nullptr;
+  const float* am = hasadd ? p.addmask + (int64_t)b * p.am_sb + (int64_t)qi * p.am_sl : nullptr;
+  // pure causal: invisible keys contribute exactly 0 -> stop at the diagonal.  With key padding
+  // every key is walked so a fully masked row reproduces the reference's uniform average.
+  int S_eff = p.S;
+  if (causal && !haskp && !hasadd) S_eff = min(p.S, qi + p.start_pos + 1);
+
+  float m = -FLT_MAX, l = 0.f, acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int j0 = wave * KPP; j0 < S_eff; j0 += 4 * KPP) {
+    const int j = j0 + grp;
+    const bool valid = j < S_eff;
+    const int jc = valid ? j : S_eff - 1;
+    float kv[VEC];
+    RowVec<T>::load(Kb + (int64_t)jc * p.k_sl + ch * VEC, kv);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) d = fmaf(qv[e], kv[e], d);
+#pragma unroll
+    for (int o_ = CPR >> 1; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
+    float t = d * p.scale;
+    if (hasadd) t = t + am[jc];
+    if (causal && jc > qi + p.start_pos) t = -FLT_MAX;
+    if (haskp && !kp[jc]) t = -FLT_MAX;
+    t = fmaxf(t, -FLT_MAX);
+    if (valid) {
+      const float mn = fmaxf(m, t);
+      const float a = __expf(m - mn), e_ = __expf(t - mn);
+      float vv[VEC];
+      RowVec<T>::load(Vb + (int64_t)jc * p.v_sl + ch * VEC, vv);
+      l = l * a + e_;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = acc[e] * a + e_ * vv[e];
+      m = mn;
+    }
+  }
+  // combine the KPP key groups of the wave (lanes with equal ch), then the 4 waves through LDS
+#pragma unroll
+  for (int o_ = CPR; o_ < 64; o_ <<= 1) {
+    const float m2 = __shfl_xor(m, o_, 64), l2 = __shfl_xor(l, o_, 64);
+    const float mn = fmaxf(m, m2);
+    const float a1 = __expf(m - mn), a2 = __expf(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = acc[e] * a1 + __shfl_xor(acc[e], o_, 64) * a2;
+    m = mn;
+  }
+  if (grp == 0) {
+    red_m[wave * KPP] = m; red_l[wave * KPP] = l;  // one slot per wave (index reuse of KPP stride)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red_o[(wave * 64 + ch) * VEC + e] = acc[e];
+  }
+  __syncthreads();
+  if (wave == 0 && grp == 0) {
+    float M_ = red_m[0];
+    for (int w = 1; w < 4; ++w) M_ = fmaxf(M_, red_m[w * KPP]);
+    float Ls = 0.f, out[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) out[e] = 0.f;
+    for (int w = 0; w < 4; ++w) {
+      const float a = __expf(red_m[w * KPP] - M_);
+      Ls += red_l[w * KPP] * a;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) out[e] += red_o[(w * 64 + ch) * VEC + e] * a;
+    }
+    T* O = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qi * p.o_sl + head * dh + ch * VEC;
+    const float inv = 1.0f / Ls;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) VyT<T>::st(O + e, out[e] * inv);
+    if (p.lse && ch == 0) p.lse[((int64_t)b * p.h + head) * p.L + qi] = M_ + __logf(Ls);
+  }
+}
+
+template <typename T>
+int launch_rowwise(const AttnParams& p, int dh, hipStream_t st, const char* who) {
+  constexpr int VEC = RowVec<T>::VEC;
+  if (dh % VEC) VY_FAIL(VY_ERR_ARG, "%s: head_dim %d not a multiple of %d", who, dh, VEC);
+  const int cpr = dh / VEC;
+  const dim3 grid(p.L, p.h, p.B), block(256);
+#define RW_GO(C) hipLaunchKernelGGL((attn_rowwise_kernel<T, C>), grid, block, 0, st, p, dh)
+  switch (cpr) {
+    case 1: RW_GO(1); break;
+    case 2: RW_GO(2); break;
+    case 4: RW_GO(4); break;
+    case 8: RW_GO(8); break;
+    case 16: RW_GO(16); break;
+    case 32: RW_GO(32); break;
+    case 64: RW_GO(64); break;
+    default: VY_FAIL(VY_ERR_UNSUPPORTED, "%s: head_dim %d unsupported (dh/%d must be a power of two <= 64)", who, dh, VEC);
+  }
+#undef RW_GO
+  VY_CHECK_LAUNCH(who);
+  return VY_OK;
+}
+
+int check_attn(const char* who, const AttnParams& p, int dh, int dtype) {
+  if (!p.q || !p.k || !p.v || !p.out) VY_FAIL(VY_ERR_ARG, "%s: null tensor", who);
+  if (p.B <= 0 || p.h <= 0 || p.hk <= 0 || p.L <= 0 || p.S <= 0 || dh <= 0)
+    VY_FAIL(VY_ERR_ARG, "%s: empty problem B=%d h=%d hk=%d L=%d S=%d dh=%d", who, p.B, p.h, p.hk, p.L, p.S, dh);
+  if (p.h % p.hk) VY_FAIL(VY_ERR_ARG, "%s: h=%d is not a multiple of hk=%d", who, p.h, p.hk);
+  if ((p.mask_kind & VY_MASK_KEYPAD) && !p.keypad) VY_FAIL(VY_ERR_ARG, "%s: keypad mask requested but NULL", who);
+  if ((p.mask_kind & VY_MASK_ADDITIVE) && !p.addmask) VY_FAIL(VY_ERR_ARG, "%s: additive mask requested but NULL", who);
+  const int vec = dtype == VY_BF16 ? 8 : 4;
+  const int64_t s[] = {p.q_sb, p.q_sh, p.q_sl, p.k_sb, p.k_sh, p.k_sl, p.v_sb, p.v_sh, p.v_sl, p.o_sb, p.o_sl};
+  for (int64_t x : s)
+    if (x % vec) VY_FAIL(VY_ERR_ARG, "%s: strides must be multiples of %d elements (16 bytes)", who, vec);
+  if ((uintptr_t)p.q % 16 || (uintptr_t)p.k % 16 || (uintptr_t)p.v % 16 || (uintptr_t)p.out % 16)
+    VY_FAIL(VY_ERR_ARG, "%s: tensors must be 16-byte aligned", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vy_attn_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl, const void* k,
+                           int64_t k_sb, int64_t k_sh, int64_t k_sl, const void* v, int64_t v_sb,
+                           int64_t v_sh, int64_t v_sl, void* out, int64_t o_sb, int64_t o_sl, float* lse,
+                           int mask_kind, int64_t start_pos, const uint8_t* keypad, int64_t kp_sb,
+                           const float* addmask, int64_t am_sb, int64_t am_sl, int64_t B, int h, int hk,
+                           int64_t L, int64_t S, int dh, float scale, int dtype, void* stream) {
+  const char* who = "vy_attn_fwd";
+  AttnParams p;
+  p.q = q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = q_sl;
+  p.k = k; p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
+  p.v = v; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
+  p.out = out; p.o_sb = o_sb; p.o_sl = o_sl; p.lse = lse;
+  p.mask_kind = mask_kind; p.start_pos = (int)start_pos;
+  p.keypad = keypad; p.kp_sb = kp_sb; p.addmask = addmask; p.am_sb = am_sb; p.am_sl = am_sl;
+  p.B = (int)B; p.h = h; p.hk = hk; p.L = (int)L; p.S = (int)S; p.scale = scale;
+  if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
+  if (int rc = check_attn(who, p, dh, dtype)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16 && (dh == 64 || dh == 128) && L > 1) {
+    const dim3 grid((unsigned)((L + 127) / 128), (unsigned)h, (unsigned)B), block(256);
+    if (dh == 64) hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(attn_fwd_mfma_kernel<128>, grid, block, 0, st, p);
+    VY_CHECK_LAUNCH(who);
+    return VY_OK;
+  }
+  if (dtype == VY_BF16) return launch_rowwise<bf16>(p, dh, st, who);
+  return launch_rowwise<float>(p, dh, st, who);
+}
+
+extern "C" int vy_attn_decode(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb,
+                              int64_t k_sh, int64_t k_sl, const void* v, int64_t v_sb, int64_t v_sh,
+                              int64_t v_sl, void* out, int64_t o_sb, int64_t B, int h, int hk, int64_t S,
+                              int dh, float scale, int dtype, void* stream) {
+  const char* who = "vy_attn_decode";
+  AttnParams p{};
+  p.q = q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = (int64_t)h * dh;  // single token: unused stride
+  p.k = k; p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
+  p.v = v; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
+  p.out = out; p.o_sb = o_sb; p.o_sl = (int64_t)h * dh; p.lse = nullptr;
+  p.mask_kind = VY_MASK_NONE; p.start_pos = 0;
+  p.B = (int)B; p.h = h; p.hk = hk; p.L = 1; p.S = (int)S; p.scale = scale;
+  if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
+  if (int rc = check_attn(who, p, dh, dtype)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16) return launch_rowwise<bf16>(p, dh, st, who);
+  return launch_rowwise<float>(p, dh, st, who);
+}

@@ -1,0 +1,101 @@
+// Common device/host helpers for libvyom_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/vyom_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define VY_LDS __attribute__((address_space(3)))
+#define VY_GLOBAL __attribute__((address_space(1)))
+
+// host-side error plumbing -------------------------------------------------------------
+void vy_set_error(const char* fmt, ...);
+#define VY_FAIL(code, ...)      \
+  do {                          \
+    vy_set_error(__VA_ARGS__);  \
+    return (code);              \
+  } while (0)
+#define VY_CHECK_LAUNCH(name)                                             \
+  do {                                                                    \
+    hipError_t e_ = hipGetLastError();                                    \
+    if (e_ != hipSuccess)                                                 \
+      VY_FAIL(VY_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_));      \
+  } while (0)
+
+static inline int64_t vy_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 16 zero bytes: source for K-tail chunks of LDS-DMA loads.
+extern __device__ uint32_t vy_zero16[4];
+
+// device helpers ------------------------------------------------------------------------
+__device__ __forceinline__ float vy_gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float vy_gelu_erf_grad(float x) {
+  // d/dx [x Phi(x)] = Phi(x) + x phi(x)
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float vy_gelu_tanh(float x) {
+  const float c = 0.79788456080286535588f;
+  return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float vy_gelu_tanh_grad(float x) {
+  const float c = 0.79788456080286535588f;
+  const float u = c * (x + 0.044715f * x * x * x);
+  const float t = tanhf(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+}
+template <int ACT>
+__device__ __forceinline__ float vy_act_fwd(float x) {
+  if constexpr (ACT == VY_ACT_GELU_ERF) return vy_gelu_erf(x);
+  else if constexpr (ACT == VY_ACT_GELU_TANH) return vy_gelu_tanh(x);
+  else return x;
+}
+template <int ACT>
+__device__ __forceinline__ float vy_act_grad(float x) {
+  if constexpr (ACT == VY_ACT_GELU_ERF) return vy_gelu_erf_grad(x);
+  else if constexpr (ACT == VY_ACT_GELU_TANH) return vy_gelu_tanh_grad(x);
+  else return 1.0f;
+}
+
+__device__ __forceinline__ float vy_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float vy_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Round an fp32 value to bf16 and back.  Goes through the bit pattern: clang evaluates __bf16
+// expressions with excess precision, so a plain (float)(bf16)x round trip may be elided.
+__device__ __forceinline__ float vy_round_bf16(float x) {
+  const bf16 b = (bf16)x;
+  const unsigned short u = __builtin_bit_cast(unsigned short, b);
+  return __builtin_bit_cast(float, (unsigned)u << 16);
+}
+
+// load/store helpers templated on the storage type
+template <typename T> struct VyT;
+template <> struct VyT<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct VyT<bf16> {
+  static __device__ __forceinline__ float ld(const bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(bf16* p, float v) { *p = (bf16)v; }
+};

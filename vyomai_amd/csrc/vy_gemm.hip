@@ -1,0 +1,565 @@
+// GEMM family for the projection / feed-forward path:  Y[M,N] = epi(X[M,K] . W[N,K]^T)
+//
+// bf16 kernel (the product path): MFMA 32x32x16, fp32 accumulate, LDS-DMA staging.
+//   * workgroup = 4 waves; tile BM x BN x 64 (default 128 x 128), double-buffered LDS;
+//   * both operands are K-contiguous ("NT"), so both MFMA fragments are 16-byte row reads
+//     (ds_read_b128) from a [rows][64] bf16 LDS image; the image is XOR-swizzled on the 16-B
+//     chunk index with (row>>1)&7, applied on the *source address* of the
+//     global_load_lds_dwordx4 (the LDS destination of an LDS-DMA is lane-linear) and again on
+//     the read -- conflict-free for the 16-lane groups of ds_read_b128;
+//   * the accumulator is kept TRANSPOSED (A operand = W fragment, B operand = X fragment), so a
+//     lane owns one output row m and 4 consecutive columns n per register quad: bias is a
+//     per-register value, residual / RoPE / head-split / stores are 8-byte row-local accesses,
+//     and rotary pairs (d, d+32) sit in the same lane and register of adjacent 32x32 blocks;
+//   * blockIdx is remapped so each XCD (private L2) walks a contiguous run of tiles that share
+//     the X row panel.
+//
+// f32 kernel (the 1e-5 parity path): same structure and epilogues on mfma_f32_32x32x2f32, whose
+// result is bit-for-bit a k-ordered fmaf chain.
+//
+// Reference semantics: nn.Linear call sites listed in include/vyom_hip.h.
+#include "vy_common.h"
+
+__device__ uint32_t vy_zero16[4] = {0, 0, 0, 0};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// epilogues.  A "quad" is 4 consecutive output columns n0..n0+3 of one row m, held by one lane.
+// ------------------------------------------------------------------------------------------
+
+template <typename T> struct Quad;
+template <> struct Quad<bf16> {
+  static __device__ __forceinline__ void load(const bf16* p, float (&v)[4]) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)t[e];
+  }
+  static __device__ __forceinline__ void store(bf16* p, const float (&v)[4]) {
+    bf16x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x4*>(p) = t;
+  }
+};
+template <> struct Quad<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+
+// plain epilogue: (+bias) -> [save pre] -> act -> (* act'(gradpre)) -> (+residual) -> store
+template <typename T>
+struct EpiPlain {
+  const T* bias;
+  const T* residual; int64_t ldr;
+  const T* gradpre;  int64_t ldg;
+  T* y;   int64_t ldy;
+  T* pre; // same ld as y
+  int vec_ok;  // all row strides % 4 == 0 and base pointers 4-element aligned
+};
+
+template <typename T, int ACT, bool GRAD>
+__device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[4], int64_t m, int n,
+                                               int N) {
+  if (n >= N) return;
+  const bool full = e.vec_ok && (n + 3 < N);
+  if (full) {
+    if (e.bias) { float b[4]; Quad<T>::load(e.bias + n, b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += b[i]; }
+    if (e.pre) Quad<T>::store(e.pre + m * e.ldy + n, v);
+    if constexpr (!GRAD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = vy_act_fwd<ACT>(v[i]);
+    } else {
+      if (e.gradpre) { float g[4]; Quad<T>::load(e.gradpre + m * e.ldg + n, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= vy_act_grad<ACT>(g[i]); }
+    }
+    if (e.residual) { float r[4]; Quad<T>::load(e.residual + m * e.ldr + n, r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += r[i]; }
+    Quad<T>::store(e.y + m * e.ldy + n, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (n + i >= N) break;
+      float x = v[i];
+      if (e.bias) x += VyT<T>::ld(e.bias + n + i);
+      if (e.pre) VyT<T>::st(e.pre + m * e.ldy + n + i, x);
+      if constexpr (!GRAD) x = vy_act_fwd<ACT>(x);
+      else if (e.gradpre) x *= vy_act_grad<ACT>(VyT<T>::ld(e.gradpre + m * e.ldg + n + i));
+      if (e.residual) x += VyT<T>::ld(e.residual + m * e.ldr + n + i);
+      VyT<T>::st(e.y + m * e.ldy + n + i, x);
+    }
+  }
+}
+
+// QKV epilogue: bias, rotary embedding on the q and k sections, head split + scatter.
+template <typename T>
+struct EpiQkv {
+  const T* bias;
+  const float* cos_tab; const float* sin_tab; int64_t pos0;
+  T* q; int64_t q_sb, q_sh, q_sl;
+  T* k; int64_t k_sb, k_sh, k_sl;
+  T* v; int64_t v_sb, v_sh, v_sl;
+  int L; int nq; int nkv;  // nq = h*dh, nkv = hk*dh
+  int dh;
+  int rope;  // 1: fused rotary (requires dh == 64, wave n-tile == one head)
+};
+
+template <typename T>
+__device__ __forceinline__ T* qkv_dest(const EpiQkv<T>& e, int64_t b, int64_t l, int n) {
+  // n: column in the packed [q | k | v] output; returns pointer to element (b, head, l, d)
+  if (n < e.nq) { const int hd = n / e.dh, d = n - hd * e.dh;
+    return e.q + b * e.q_sb + hd * e.q_sh + l * e.q_sl + d; }
+  n -= e.nq;
+  if (n < e.nkv) { const int hd = n / e.dh, d = n - hd * e.dh;
+    return e.k + b * e.k_sb + hd * e.k_sh + l * e.k_sl + d; }
+  n -= e.nkv;
+  const int hd = n / e.dh, d = n - hd * e.dh;
+  return e.v + b * e.v_sb + hd * e.v_sh + l * e.v_sl + d;
+}
+
+template <typename T> __device__ __forceinline__ float round_like(float x);
+template <> __device__ __forceinline__ float round_like<bf16>(float x) { return vy_round_bf16(x); }
+template <> __device__ __forceinline__ float round_like<float>(float x) { return x; }
+
+// lo/hi: the two 32-column blocks of one 64-wide head (d = dlo..dlo+3 and d+32)
+template <typename T>
+__device__ __forceinline__ void epi_qkv_pair(const EpiQkv<T>& e, float (&lo)[4], float (&hi)[4],
+                                             int64_t m, int n_lo, int N) {
+  if (n_lo >= N) return;
+  const int64_t b = m / e.L, l = m - b * e.L;
+  if (e.bias) {
+    float b0[4], b1[4];
+    Quad<T>::load(e.bias + n_lo, b0); Quad<T>::load(e.bias + n_lo + 32, b1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { lo[i] += b0[i]; hi[i] += b1[i]; }
+  }
+  if (e.rope && n_lo < e.nq + e.nkv) {
+    // reference: q*cos + rotate_half(q)*sin with cos/sin cast to q.dtype first
+    // (VyomAI/layers/positional_embeddings.py:173-181); products are formed on the
+    // storage-rounded projection like the reference's separate Linear -> RoPE ops.
+    const int d = n_lo & 31;  // head base is a multiple of 64, n_lo is in the low half
+    const float* cp = e.cos_tab + (e.pos0 + l) * 32 + d;
+    const float* sp = e.sin_tab + (e.pos0 + l) * 32 + d;
+    const f32x4 c4 = *reinterpret_cast<const f32x4*>(cp);
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float c = round_like<T>(c4[i]), s = round_like<T>(s4[i]);
+      const float a = round_like<T>(lo[i]), bb = round_like<T>(hi[i]);
+      // each product rounded to the storage type before the add, as the reference's
+      // (q * cos) + (rotate_half(q) * sin) evaluates it
+      lo[i] = round_like<T>(a * c) - round_like<T>(bb * s);
+      hi[i] = round_like<T>(bb * c) + round_like<T>(a * s);
+    }
+  }
+  Quad<T>::store(qkv_dest(e, b, l, n_lo), lo);
+  Quad<T>::store(qkv_dest(e, b, l, n_lo + 32), hi);
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_qkv_quad(const EpiQkv<T>& e, float (&v)[4], int64_t m, int n, int N) {
+  if (n >= N) return;
+  const int64_t b = m / e.L, l = m - b * e.L;
+  if (e.bias) { float b0[4]; Quad<T>::load(e.bias + n, b0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += b0[i]; }
+  Quad<T>::store(qkv_dest(e, b, l, n), v);
+}
+
+// XCD-aware bijective block remap: blocks b, b+8, ... share an XCD (round-robin dispatch), give
+// each XCD a contiguous run of tile ids.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------
+constexpr int BK = 64;            // k elements per stage
+constexpr int ROWB = BK * 2;      // bytes per LDS row (128)
+
+template <int TM, int TN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  constexpr int GX = BM / 8 / 4, GW = BN / 8 / 4;  // 8-row LDS-DMA pieces per wave per stage
+  constexpr int STAGE = (BM + BN) * ROWB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-lane LDS-DMA source pointers (row clamped for M/N tails, chunk pre-swizzled) ----
+  const int lrow = lane >> 3, slot = lane & 7;
+  const bf16* xsrc[GX]; int xk[GX];
+  const bf16* wsrc[GW]; int wk[GW];
+#pragma unroll
+  for (int t = 0; t < GX; ++t) {
+    const int R = (wave * GX + t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gm = m0 + R; gm = gm < M ? gm : M - 1;
+    xsrc[t] = X + (int64_t)gm * ldx + g * 8;
+    xk[t] = g * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int R = (wave * GW + t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gn = n0 + R; gn = gn < N ? gn : N - 1;
+    wsrc[t] = W + (int64_t)gn * ldw + g * 8;
+    wk[t] = g * 8;
+  }
+  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
+  const bool ktail = (K % BK) != 0;
+  const int KT = (K + BK - 1) / BK;
+
+  auto stage = [&](int kt, int buf) {
+    char* xb = smem + buf * STAGE;
+    char* wb = xb + BM * ROWB;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int t = 0; t < GX; ++t) {
+      const bf16* s = xsrc[t] + k0;
+      if (ktail && k0 + xk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
+                                       (VY_LDS void*)(xb + (wave * GX + t) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < GW; ++t) {
+      const bf16* s = wsrc[t] + k0;
+      if (ktail && k0 + wk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
+                                       (VY_LDS void*)(wb + (wave * GW + t) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets: row = base32 + (lane&31); chunk = 2*ks + (lane>>5), swizzle (row>>1)&7
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  const int xrow_off = (wm * 32 * TM + fr) * ROWB;
+  const int wrow_off = (wn * 32 * TN + fr) * ROWB;
+
+  stage(0, 0);
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0)
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+    const char* xb = smem + cur * STAGE;
+    const char* wb = xb + BM * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = (((ks * 2 + fh) ^ fsw) << 4);
+      bf16x8 wf[TN], xf[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+        wf[i] = *reinterpret_cast<const bf16x8*>(wb + wrow_off + i * 32 * ROWB + coff);
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        xf[j] = *reinterpret_cast<const bf16x8*>(xb + xrow_off + j * 32 * ROWB + coff);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns row m, register quad rg owns columns nb + 8*rg + 4*fh + (0..3) ----
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+    const int64_t m = m0 + wm * 32 * TM + j * 32 + fr;
+    if (m >= M) continue;
+    if constexpr (EPI == 0) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float v[4] = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
+          epi_plain_quad<bf16, ACT, GRAD>(ep, v, m, n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, N);
+        }
+    } else {
+      bool did_rope = false;
+      if constexpr (TN % 2 == 0) {  // rotary pairs need a 64-wide (one head) wave tile
+        if (eq.rope) {
+          did_rope = true;
+#pragma unroll
+          for (int i = 0; i < TN; i += 2)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            float lo[4] = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
+            float hi[4] = {acc[i + 1][j][4 * rg], acc[i + 1][j][4 * rg + 1], acc[i + 1][j][4 * rg + 2], acc[i + 1][j][4 * rg + 3]};
+            epi_qkv_pair<bf16>(eq, lo, hi, m, n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, N);
+          }
+        }
+      }
+      if (!did_rope) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            float v[4] = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
+            epi_qkv_quad<bf16>(eq, v, m, n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, N);
+          }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 MFMA kernel (parity path): 64x64 tile, BK=16, 4 waves of 32x32, mfma_f32_32x32x2f32
+// ------------------------------------------------------------------------------------------
+constexpr int FBK = 16;
+constexpr int FLD = FBK + 1;  // padded LDS row (floats): conflict-free ds_read_b32 column reads
+
+template <int EPI, int ACT, bool GRAD>
+__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, EpiPlain<float> ep, EpiQkv<float> eq) {
+  __shared__ float xs[64 * FLD];
+  __shared__ float ws[64 * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+  const int m0 = tile_m * 64, n0 = tile_n * 64;
+  const int lr = tid >> 2, lc = (tid & 3) * 4;  // loader: row 0..63, 4 floats at column lc
+  int gm = m0 + lr; gm = gm < M ? gm : M - 1;
+  int gn = n0 + lr; gn = gn < N ? gn : N - 1;
+  const float* xp = X + (int64_t)gm * ldx + lc;
+  const float* wp = W + (int64_t)gn * ldw + lc;
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += FBK) {
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
+    if (k0 + lc < K) {  // K % 4 == 0 is required, so a float4 is all-in or all-out
+      xv = *reinterpret_cast<const f32x4*>(xp + k0);
+      wv = *reinterpret_cast<const f32x4*>(wp + k0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xs[lr * FLD + lc + e] = xv[e]; ws[lr * FLD + lc + e] = wv[e]; }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < FBK / 2; ++kk) {
+      const float a = ws[(wn * 32 + fr) * FLD + 2 * kk + fh];
+      const float b = xs[(wm * 32 + fr) * FLD + 2 * kk + fh];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int64_t m = m0 + wm * 32 + fr;
+  if (m >= M) return;
+  if constexpr (EPI == 0) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float v[4] = {acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]};
+      epi_plain_quad<float, ACT, GRAD>(ep, v, m, n0 + wn * 32 + 8 * rg + 4 * fh, N);
+    }
+  } else {
+    // rotary pairs (d, d+32) live in the sibling wave here, so the f32 path never fuses RoPE:
+    // the host applies vy_rope_fwd afterwards.
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float v[4] = {acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]};
+      epi_qkv_quad<float>(eq, v, m, n0 + wn * 32 + 8 * rg + 4 * fh, N);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <int EPI, int ACT, bool GRAD>
+int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t M, int64_t N,
+                int64_t K, const EpiPlain<bf16>& ep, const EpiQkv<bf16>& eq, hipStream_t st) {
+  if (M <= 32) {  // skinny (decode): 32 x 128 tiles keep more workgroups in flight
+    const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 32);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<1, 1, 1, 4, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
+                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+  } else {
+    const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, 2, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
+                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+  }
+  return 0;
+}
+
+template <int EPI, int ACT, bool GRAD>
+int launch_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int64_t N,
+               int64_t K, const EpiPlain<float>& ep, const EpiQkv<float>& eq, hipStream_t st) {
+  const int tn = (int)vy_cdiv(N, 64), tm = (int)vy_cdiv(M, 64);
+  hipLaunchKernelGGL((gemm_nt_f32_kernel<EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0, st, X, ldx, W,
+                     ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+  return 0;
+}
+
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <typename T>
+int check_operands(const char* who, const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M,
+                   int64_t N, int64_t K) {
+  const int vec = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  if (!x || !w) VY_FAIL(VY_ERR_ARG, "%s: null operand", who);
+  if (M <= 0 || N <= 0 || K <= 0) VY_FAIL(VY_ERR_ARG, "%s: empty problem M=%ld N=%ld K=%ld", who, (long)M, (long)N, (long)K);
+  if (M > INT32_MAX || N > INT32_MAX || K > INT32_MAX) VY_FAIL(VY_ERR_ARG, "%s: dimension overflow", who);
+  if (K % vec) VY_FAIL(VY_ERR_ARG, "%s: K=%ld must be a multiple of %d", who, (long)K, vec);
+  if (ldx % vec || ldw % vec || !aligned_to(x, 16) || !aligned_to(w, 16))
+    VY_FAIL(VY_ERR_ARG, "%s: operand rows must be 16-byte aligned (ldx=%ld ldw=%ld)", who, (long)ldx, (long)ldw);
+  if (ldx < K || ldw < K) VY_FAIL(VY_ERR_ARG, "%s: leading dimension smaller than K", who);
+  return 0;
+}
+
+template <typename T>
+int linear_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                const void* residual, int64_t ldr, const void* gradpre, int64_t ldg, void* y,
+                int64_t ldy, void* pre_out, int64_t M, int64_t N, int64_t K, int act, bool grad,
+                hipStream_t st, const char* who) {
+  if (int rc = check_operands<T>(who, x, ldx, w, ldw, M, N, K)) return rc;
+  if (!y) VY_FAIL(VY_ERR_ARG, "%s: null output", who);
+  if (ldy < N) VY_FAIL(VY_ERR_ARG, "%s: ldy < N", who);
+  EpiPlain<T> ep;
+  ep.bias = (const T*)bias; ep.residual = (const T*)residual; ep.ldr = ldr;
+  ep.gradpre = (const T*)gradpre; ep.ldg = ldg; ep.y = (T*)y; ep.ldy = ldy; ep.pre = (T*)pre_out;
+  const size_t qa = 4 * sizeof(T);
+  ep.vec_ok = (ldy % 4 == 0) && aligned_to(y, qa) && (!bias || aligned_to(bias, qa)) &&
+              (!residual || (ldr % 4 == 0 && aligned_to(residual, qa))) &&
+              (!gradpre || (ldg % 4 == 0 && aligned_to(gradpre, qa))) &&
+              (!pre_out || aligned_to(pre_out, qa));
+  EpiQkv<T> eq{};
+#define VY_GO(ACT_, GRAD_)                                                                              \
+  do {                                                                                                  \
+    if constexpr (sizeof(T) == 2)                                                                       \
+      launch_bf16<0, ACT_, GRAD_>((const bf16*)x, ldx, (const bf16*)w, ldw, M, N, K,                    \
+                                  *reinterpret_cast<EpiPlain<bf16>*>(&ep), *reinterpret_cast<EpiQkv<bf16>*>(&eq), st); \
+    else                                                                                                \
+      launch_f32<0, ACT_, GRAD_>((const float*)x, ldx, (const float*)w, ldw, M, N, K,                   \
+                                 *reinterpret_cast<EpiPlain<float>*>(&ep), *reinterpret_cast<EpiQkv<float>*>(&eq), st); \
+  } while (0)
+  if (!grad) {
+    if (act == VY_ACT_NONE) VY_GO(VY_ACT_NONE, false);
+    else if (act == VY_ACT_GELU_ERF) VY_GO(VY_ACT_GELU_ERF, false);
+    else if (act == VY_ACT_GELU_TANH) VY_GO(VY_ACT_GELU_TANH, false);
+    else VY_FAIL(VY_ERR_ARG, "%s: unknown activation %d", who, act);
+  } else {
+    if (act == VY_ACT_NONE || !gradpre) VY_GO(VY_ACT_NONE, true);
+    else if (act == VY_ACT_GELU_ERF) VY_GO(VY_ACT_GELU_ERF, true);
+    else if (act == VY_ACT_GELU_TANH) VY_GO(VY_ACT_GELU_TANH, true);
+    else VY_FAIL(VY_ERR_ARG, "%s: unknown activation %d", who, act);
+  }
+#undef VY_GO
+  VY_CHECK_LAUNCH(who);
+  return VY_OK;
+}
+
+template <typename T>
+int qkv_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+             const float* cos_tab, const float* sin_tab, int64_t pos0, void* q, int64_t q_sb,
+             int64_t q_sh, int64_t q_sl, void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl, void* v,
+             int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t L, int64_t K, int h, int hk,
+             int dh, hipStream_t st) {
+  const char* who = "vy_qkv_rope_fwd";
+  const int64_t M = B * L, N = (int64_t)(h + 2 * hk) * dh;
+  if (int rc = check_operands<T>(who, x, ldx, w, ldw, M, N, K)) return rc;
+  if (!q || !k || !v) VY_FAIL(VY_ERR_ARG, "%s: null output", who);
+  if (h <= 0 || hk <= 0 || h % hk) VY_FAIL(VY_ERR_ARG, "%s: h=%d must be a positive multiple of hk=%d", who, h, hk);
+  if (dh % 4) VY_FAIL(VY_ERR_ARG, "%s: head_dim %d must be a multiple of 4", who, dh);
+  if ((cos_tab == nullptr) != (sin_tab == nullptr)) VY_FAIL(VY_ERR_ARG, "%s: cos/sin must both be given", who);
+  const size_t qa = 4 * sizeof(T);
+  const int64_t strides[] = {q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl};
+  for (int64_t s : strides)
+    if (s % 4) VY_FAIL(VY_ERR_ARG, "%s: output strides must be multiples of 4 elements", who);
+  if (!aligned_to(q, qa) || !aligned_to(k, qa) || !aligned_to(v, qa) || (bias && !aligned_to(bias, qa)))
+    VY_FAIL(VY_ERR_ARG, "%s: outputs/bias must be 4-element aligned", who);
+  EpiQkv<T> eq;
+  eq.bias = (const T*)bias; eq.cos_tab = cos_tab; eq.sin_tab = sin_tab; eq.pos0 = pos0;
+  eq.q = (T*)q; eq.q_sb = q_sb; eq.q_sh = q_sh; eq.q_sl = q_sl;
+  eq.k = (T*)k; eq.k_sb = k_sb; eq.k_sh = k_sh; eq.k_sl = k_sl;
+  eq.v = (T*)v; eq.v_sb = v_sb; eq.v_sh = v_sh; eq.v_sl = v_sl;
+  eq.L = (int)L; eq.nq = h * dh; eq.nkv = hk * dh; eq.dh = dh;
+  // fused rotary: bf16 kernel with 64-wide wave tiles and dh == 64 (pairs are register-local)
+  const bool fuse = cos_tab && sizeof(T) == 2 && dh == 64 && M > 32;
+  eq.rope = fuse ? 1 : 0;
+  EpiPlain<T> ep{};
+  if constexpr (sizeof(T) == 2)
+    launch_bf16<1, VY_ACT_NONE, false>((const bf16*)x, ldx, (const bf16*)w, ldw, M, N, K,
+                                       *reinterpret_cast<EpiPlain<bf16>*>(&ep), *reinterpret_cast<EpiQkv<bf16>*>(&eq), st);
+  else
+    launch_f32<1, VY_ACT_NONE, false>((const float*)x, ldx, (const float*)w, ldw, M, N, K,
+                                      *reinterpret_cast<EpiPlain<float>*>(&ep), *reinterpret_cast<EpiQkv<float>*>(&eq), st);
+  VY_CHECK_LAUNCH(who);
+  if (cos_tab && !fuse) {
+    const int vdt = sizeof(T) == 2 ? VY_BF16 : VY_F32;
+    if (int rc = vy_rope_fwd(q, q_sb, q_sh, q_sl, cos_tab, sin_tab, pos0, B, h, L, dh, 0, vdt, st)) return rc;
+    if (int rc = vy_rope_fwd(k, k_sb, k_sh, k_sl, cos_tab, sin_tab, pos0, B, hk, L, dh, 0, vdt, st)) return rc;
+  }
+  return VY_OK;
+}
+
+}  // namespace
+
+extern "C" int vy_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                             const void* residual, int64_t ldr, void* y, int64_t ldy, void* pre_out,
+                             int64_t M, int64_t N, int64_t K, int act, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16)
+    return linear_impl<bf16>(x, ldx, w, ldw, bias, residual, ldr, nullptr, 0, y, ldy, pre_out, M, N, K, act, false, st, "vy_linear_fwd");
+  if (dtype == VY_F32)
+    return linear_impl<float>(x, ldx, w, ldw, bias, residual, ldr, nullptr, 0, y, ldy, pre_out, M, N, K, act, false, st, "vy_linear_fwd");
+  VY_FAIL(VY_ERR_ARG, "vy_linear_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int vy_linear_dgrad(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const void* pre,
+                               int64_t ldpre, int act, const void* add_to, int64_t ldadd, void* dx,
+                               int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+  // dX[M,K] = dY[M,N] . W[N,K] = dY . (W^T)^T with W^T stored [K,N]: an NT GEMM whose
+  // "N" is K and whose contraction runs over N.
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16)
+    return linear_impl<bf16>(dy, lddy, wt, ldwt, nullptr, add_to, ldadd, pre, ldpre, dx, lddx, nullptr, M, K, N, act, true, st, "vy_linear_dgrad");
+  if (dtype == VY_F32)
+    return linear_impl<float>(dy, lddy, wt, ldwt, nullptr, add_to, ldadd, pre, ldpre, dx, lddx, nullptr, M, K, N, act, true, st, "vy_linear_dgrad");
+  VY_FAIL(VY_ERR_ARG, "vy_linear_dgrad: bad dtype %d", dtype);
+}
+
+extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                               const float* cos_tab, const float* sin_tab, int64_t pos0, void* q,
+                               int64_t q_sb, int64_t q_sh, int64_t q_sl, void* k, int64_t k_sb,
+                               int64_t k_sh, int64_t k_sl, void* v, int64_t v_sb, int64_t v_sh,
+                               int64_t v_sl, int64_t B, int64_t L, int64_t K, int h, int hk, int dh,
+                               int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16)
+    return qkv_impl<bf16>(x, ldx, w, ldw, bias, cos_tab, sin_tab, pos0, q, q_sb, q_sh, q_sl, k, k_sb, k_sh, k_sl, v, v_sb, v_sh, v_sl, B, L, K, h, hk, dh, st);
+  if (dtype == VY_F32)
+    return qkv_impl<float>(x, ldx, w, ldw, bias, cos_tab, sin_tab, pos0, q, q_sb, q_sh, q_sl, k, k_sb, k_sh, k_sl, v, v_sb, v_sh, v_sl, B, L, K, h, hk, dh, st);
+  VY_FAIL(VY_ERR_ARG, "vy_qkv_rope_fwd: bad dtype %d", dtype);
+}

@@ -1,0 +1,421 @@
+// HBM-bound row kernels of the block: LayerNorm forward/backward, standalone RoPE, casts,
+// transposes and the fused AdamW step.  All are one pass over their operands with 16-byte
+// accesses per lane; LayerNorm keeps the whole row in registers (one wave per row).
+#include "vy_common.h"
+#include <stdarg.h>
+
+// ---- error string ------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void vy_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* vy_last_error(void) { return g_err; }
+extern "C" int vy_abi_version(void) { return 1; }
+
+namespace {
+
+template <typename T> struct Chunk;  // one 16-byte chunk = VEC elements
+template <> struct Chunk<bf16> {
+  static constexpr int VEC = 8;
+  static __device__ __forceinline__ void load(const bf16* p, float* v) {
+    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+  static __device__ __forceinline__ void store(bf16* p, const float* v) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+template <> struct Chunk<float> {
+  static constexpr int VEC = 4;
+  static __device__ __forceinline__ void load(const float* p, float* v) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  }
+  static __device__ __forceinline__ void store(float* p, const float* v) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+
+// ---- LayerNorm forward: one wave per row, CH chunks per lane -------------------------------
+// mean, then variance about the mean (two reductions on registers): the same two-pass
+// formulation as aten's CPU LayerNorm closely enough for 1e-6 agreement.
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, int64_t ldx,
+                                                            const T* __restrict__ gamma,
+                                                            const T* __restrict__ beta, T* __restrict__ y,
+                                                            int64_t ldy, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int64_t M, int N,
+                                                            float eps) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = N / VEC;
+  float v[CH][VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      Chunk<T>::load(x + row * ldx + (int64_t)ch * VEC, v[c]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s += v[c][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[c][e] = 0.f;
+    }
+  }
+  const float mean = vy_wave_sum(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    }
+  }
+  const float var = vy_wave_sum(q) / (float)N;
+  const float rstd = rsqrtf(var + eps);
+  // rsqrtf is approximate on AMD; one Newton step brings it to fp32 round-off
+  const float rstd_r = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      float g[VEC], b[VEC], o[VEC];
+      Chunk<T>::load(gamma + (int64_t)ch * VEC, g);
+      Chunk<T>::load(beta + (int64_t)ch * VEC, b);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = (v[c][e] - mean) * rstd_r * g[e] + b[e];
+      Chunk<T>::store(y + row * ldy + (int64_t)ch * VEC, o);
+    }
+  }
+  if (lane == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd_r;
+  }
+}
+
+// ---- LayerNorm backward -------------------------------------------------------------------
+// wave w of the grid walks rows w, w+W, ...; a lane always owns the same columns, so dgamma /
+// dbeta partials accumulate in registers and are written once per wave into ws[w][N].
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx,
+    const T* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+    T* __restrict__ dx, int64_t lddx, float* __restrict__ ws, int64_t M, int N, int W) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= W) return;
+  const int nch = N / VEC;
+  float g[CH][VEC], dg[CH][VEC], db[CH][VEC];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { dg[c][e] = 0.f; db[c][e] = 0.f; g[c][e] = 0.f; }
+    if (ch < nch) Chunk<T>::load(gamma + (int64_t)ch * VEC, g[c]);
+  }
+  for (int64_t row = wid; row < M; row += W) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[CH][VEC], gy[CH][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        float xv[VEC], dv[VEC];
+        Chunk<T>::load(x + row * ldx + (int64_t)ch * VEC, xv);
+        Chunk<T>::load(dy + row * lddy + (int64_t)ch * VEC, dv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          xh[c][e] = (xv[e] - mu) * rs;
+          gy[c][e] = dv[e] * g[c][e];
+          s1 += gy[c][e];
+          s2 += gy[c][e] * xh[c][e];
+          dg[c][e] += dv[e] * xh[c][e];
+          db[c][e] += dv[e];
+        }
+      }
+    }
+    s1 = vy_wave_sum(s1) / (float)N;
+    s2 = vy_wave_sum(s2) / (float)N;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = rs * (gy[c][e] - s1 - xh[c][e] * s2);
+        Chunk<T>::store(dx + row * lddx + (int64_t)ch * VEC, o);
+      }
+    }
+  }
+  float* wg = ws + (int64_t)wid * N;
+  float* wb = ws + (int64_t)W * N + (int64_t)wid * N;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { wg[ch * VEC + e] = dg[c][e]; wb[ch * VEC + e] = db[c][e]; }
+    }
+  }
+}
+
+// column sums of the [W, N] partial slabs: out = beta*out + sum_w ws[w][n]
+__global__ void colsum_partials_kernel(const float* __restrict__ ws, int W, int N, float* __restrict__ out0,
+                                       float* __restrict__ out1, float beta) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float a = 0.f, b = 0.f;
+  for (int w = 0; w < W; ++w) { a += ws[(int64_t)w * N + n]; b += ws[(int64_t)(W + w) * N + n]; }
+  if (out0) out0[n] = (beta != 0.f ? beta * out0[n] : 0.f) + a;
+  if (out1) out1[n] = (beta != 0.f ? beta * out1[n] : 0.f) + b;
+}
+
+// ---- RoPE (standalone, in place) ------------------------------------------------------------
+// thread = (b, head, l, pair i): a = x[i], b = x[i + dh/2]
+template <typename T>
+__device__ __forceinline__ float rl(float x) { return x; }
+template <>
+__device__ __forceinline__ float rl<bf16>(float x) { return vy_round_bf16(x); }
+
+template <typename T>
+__global__ void rope_kernel(T* __restrict__ x, int64_t sb, int64_t sh, int64_t sl,
+                            const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                            int64_t pos0, int64_t B, int heads, int64_t L, int dh, int inverse) {
+  const int half = dh >> 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = B * heads * L * half;
+  if (idx >= total) return;
+  const int i = (int)(idx % half);
+  int64_t r = idx / half;
+  const int64_t l = r % L; r /= L;
+  const int hd = (int)(r % heads);
+  const int64_t b = r / heads;
+  T* p = x + b * sb + hd * sh + l * sl;
+  const float c = rl<T>(cos_tab[(pos0 + l) * half + i]);
+  float s = rl<T>(sin_tab[(pos0 + l) * half + i]);
+  if (inverse) s = -s;
+  const float a = VyT<T>::ld(p + i), bb = VyT<T>::ld(p + i + half);
+  // reference: (q * cos) + (rotate_half(q) * sin), every op rounded to q.dtype
+  // (VyomAI/layers/positional_embeddings.py:178-181)
+  VyT<T>::st(p + i, rl<T>(a * c) + rl<T>(-bb * s));
+  VyT<T>::st(p + i + half, rl<T>(bb * c) + rl<T>(a * s));
+}
+
+// ---- cast / transpose / adamw -----------------------------------------------------------------
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i + e < n) dst[i + e] = (D)(float)src[i + e];
+  }
+}
+
+template <typename T>
+__global__ void transpose_kernel(const T* __restrict__ in, int64_t ldin, T* __restrict__ out, int64_t ldout,
+                                 int R, int C) {
+  __shared__ T tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < R && c < C) tile[i][tx] = in[(int64_t)r * ldin + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) out[(int64_t)c * ldout + r] = tile[tx][i];
+  }
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, bf16* __restrict__ pb, int64_t n, float lr, float b1,
+                             float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    if (i + 3 < n) {
+      f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mv = *reinterpret_cast<f32x4*>(m + i);
+      f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gg = gv[e] * gscale;
+        pv[e] *= (1.0f - lr * wd);
+        mv[e] = b1 * mv[e] + (1.0f - b1) * gg;
+        vv[e] = b2 * vv[e] + (1.0f - b2) * gg * gg;
+        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+        pv[e] -= (lr / bc1) * (mv[e] / denom);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pv;
+      *reinterpret_cast<f32x4*>(m + i) = mv;
+      *reinterpret_cast<f32x4*>(v + i) = vv;
+      if (pb) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)pv[e];
+        *reinterpret_cast<bf16x4*>(pb + i) = o;
+      }
+    } else {
+      for (int e = 0; e < 4 && i + e < n; ++e) {
+        const float gg = g[i + e] * gscale;
+        float pv = p[i + e] * (1.0f - lr * wd);
+        const float mv = b1 * m[i + e] + (1.0f - b1) * gg;
+        const float vv = b2 * v[i + e] + (1.0f - b2) * gg * gg;
+        pv -= (lr / bc1) * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+        p[i + e] = pv; m[i + e] = mv; v[i + e] = vv;
+        if (pb) pb[i + e] = (bf16)pv;
+      }
+    }
+  }
+}
+
+template <typename T>
+int ln_fwd_dispatch(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
+                    float* mean, float* rstd, int64_t M, int64_t N, float eps, hipStream_t st) {
+  constexpr int VEC = Chunk<T>::VEC;
+  if (N % VEC || ldx % VEC || ldy % VEC) VY_FAIL(VY_ERR_ARG, "vy_layernorm_fwd: N/ld must be multiples of %d", VEC);
+  const int nch = (int)(N / VEC);
+  const dim3 grid((unsigned)vy_cdiv(M, 4)), block(256);
+#define LN_GO(CH)                                                                                       \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<T, CH>), grid, block, 0, st, (const T*)x, ldx, (const T*)gamma, \
+                     (const T*)beta, (T*)y, ldy, mean, rstd, M, (int)N, eps)
+  if (nch <= 64) LN_GO(1);
+  else if (nch <= 128) LN_GO(2);
+  else if (nch <= 256) LN_GO(4);
+  else if (nch <= 512) LN_GO(8);
+  else if (nch <= 1024) LN_GO(16);
+  else VY_FAIL(VY_ERR_UNSUPPORTED, "vy_layernorm_fwd: N=%ld too wide", (long)N);
+#undef LN_GO
+  VY_CHECK_LAUNCH("vy_layernorm_fwd");
+  return VY_OK;
+}
+
+template <typename T>
+int ln_bwd_dispatch(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
+                    const float* mean, const float* rstd, void* dx, int64_t lddx, float* dgamma,
+                    float* dbeta, float beta, float* ws, int64_t M, int64_t N, hipStream_t st) {
+  constexpr int VEC = Chunk<T>::VEC;
+  if (N % VEC || ldx % VEC || lddy % VEC || lddx % VEC) VY_FAIL(VY_ERR_ARG, "vy_layernorm_bwd: N/ld must be multiples of %d", VEC);
+  const int nch = (int)(N / VEC);
+  const int W = (int)vy_layernorm_bwd_ws_rows(M);
+  const dim3 grid((unsigned)vy_cdiv(W, 4)), block(256);
+#define LN_GO(CH)                                                                                        \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, CH>), grid, block, 0, st, (const T*)dy, lddy, (const T*)x, ldx, \
+                     (const T*)gamma, mean, rstd, (T*)dx, lddx, ws, M, (int)N, W)
+  if (nch <= 64) LN_GO(1);
+  else if (nch <= 128) LN_GO(2);
+  else if (nch <= 256) LN_GO(4);
+  else VY_FAIL(VY_ERR_UNSUPPORTED, "vy_layernorm_bwd: N=%ld too wide", (long)N);
+#undef LN_GO
+  VY_CHECK_LAUNCH("vy_layernorm_bwd");
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)vy_cdiv(N, 256)), dim3(256), 0, st, ws, W, (int)N,
+                     dgamma, dbeta, beta);
+  VY_CHECK_LAUNCH("vy_layernorm_bwd(colsum)");
+  return VY_OK;
+}
+
+}  // namespace
+
+extern "C" int vy_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y,
+                                int64_t ldy, float* mean, float* rstd, int64_t M, int64_t N, float eps,
+                                int dtype, void* stream) {
+  if (!x || !gamma || !beta || !y || M <= 0 || N <= 0) VY_FAIL(VY_ERR_ARG, "vy_layernorm_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16) return ln_fwd_dispatch<bf16>(x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, st);
+  if (dtype == VY_F32) return ln_fwd_dispatch<float>(x, ldx, gamma, beta, y, ldy, mean, rstd, M, N, eps, st);
+  VY_FAIL(VY_ERR_ARG, "vy_layernorm_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int64_t vy_layernorm_bwd_ws_rows(int64_t M) { return M < 1024 ? (M < 1 ? 1 : M) : 1024; }
+
+extern "C" int vy_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
+                                const float* mean, const float* rstd, void* dx, int64_t lddx, float* dgamma,
+                                float* dbeta, float beta, float* ws, int64_t M, int64_t N, int dtype,
+                                void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !ws || M <= 0 || N <= 0)
+    VY_FAIL(VY_ERR_ARG, "vy_layernorm_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16) return ln_bwd_dispatch<bf16>(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dgamma, dbeta, beta, ws, M, N, st);
+  if (dtype == VY_F32) return ln_bwd_dispatch<float>(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dgamma, dbeta, beta, ws, M, N, st);
+  VY_FAIL(VY_ERR_ARG, "vy_layernorm_bwd: bad dtype %d", dtype);
+}
+
+extern "C" int vy_rope_fwd(void* x, int64_t sb, int64_t sh, int64_t sl, const float* cos_tab,
+                           const float* sin_tab, int64_t pos0, int64_t B, int heads, int64_t L, int dh,
+                           int inverse, int dtype, void* stream) {
+  if (!x || !cos_tab || !sin_tab || dh % 2 || B <= 0 || heads <= 0 || L <= 0)
+    VY_FAIL(VY_ERR_ARG, "vy_rope_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = B * heads * L * (dh / 2);
+  const dim3 grid((unsigned)vy_cdiv(total, 256)), block(256);
+  if (dtype == VY_BF16)
+    hipLaunchKernelGGL(rope_kernel<bf16>, grid, block, 0, st, (bf16*)x, sb, sh, sl, cos_tab, sin_tab, pos0, B, heads, L, dh, inverse);
+  else if (dtype == VY_F32)
+    hipLaunchKernelGGL(rope_kernel<float>, grid, block, 0, st, (float*)x, sb, sh, sl, cos_tab, sin_tab, pos0, B, heads, L, dh, inverse);
+  else VY_FAIL(VY_ERR_ARG, "vy_rope_fwd: bad dtype %d", dtype);
+  VY_CHECK_LAUNCH("vy_rope_fwd");
+  return VY_OK;
+}
+
+extern "C" int vy_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
+  if (!src || !dst || n < 0) VY_FAIL(VY_ERR_ARG, "vy_cast: bad arguments");
+  if (n == 0) return VY_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = vy_cdiv(n, 1024);
+  const dim3 grid((unsigned)(want < 4096 ? want : 4096)), block(256);
+  if (src_dtype == VY_F32 && dst_dtype == VY_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16>), grid, block, 0, st, (const float*)src, (bf16*)dst, n);
+  else if (src_dtype == VY_BF16 && dst_dtype == VY_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16, float>), grid, block, 0, st, (const bf16*)src, (float*)dst, n);
+  else VY_FAIL(VY_ERR_ARG, "vy_cast: unsupported %d -> %d", src_dtype, dst_dtype);
+  VY_CHECK_LAUNCH("vy_cast");
+  return VY_OK;
+}
+
+extern "C" int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t R, int64_t C,
+                            int dtype, void* stream) {
+  if (!in || !out || R <= 0 || C <= 0) VY_FAIL(VY_ERR_ARG, "vy_transpose: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)vy_cdiv(C, 32), (unsigned)vy_cdiv(R, 32)), block(256);
+  if (dtype == VY_BF16)
+    hipLaunchKernelGGL(transpose_kernel<bf16>, grid, block, 0, st, (const bf16*)in, ldin, (bf16*)out, ldout, (int)R, (int)C);
+  else if (dtype == VY_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, st, (const float*)in, ldin, (float*)out, ldout, (int)R, (int)C);
+  else VY_FAIL(VY_ERR_ARG, "vy_transpose: bad dtype %d", dtype);
+  VY_CHECK_LAUNCH("vy_transpose");
+  return VY_OK;
+}
+
+extern "C" int vy_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                             float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step <= 0) VY_FAIL(VY_ERR_ARG, "vy_adamw_step: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  const int64_t want = vy_cdiv(n, 1024);
+  const dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
+  hipLaunchKernelGGL(adamw_kernel, grid, block, 0, st, p, g, m, v, (bf16*)p_bf16, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2s, grad_scale);
+  VY_CHECK_LAUNCH("vy_adamw_step");
+  return VY_OK;
+}

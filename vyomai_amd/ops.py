@@ -1,0 +1,176 @@
+"""Tensor-level wrappers over the C ABI (include/vyom_hip.h).
+
+PyTorch is used for device memory and the current HIP stream only; every computation below is a
+call into libvyom_hip.so.  All functions require CUDA (ROCm) tensors and raise otherwise -- there
+is no CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import call, dtype_code
+
+Tensor = torch.Tensor
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_gpu(*ts: Optional[Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VyomHipError(
+                "vyomai_amd ops run on MI355X only: got a CPU tensor (no CPU fallback exists; "
+                "move the module and its inputs to 'cuda')"
+            )
+
+
+def _rows(x: Tensor) -> Tensor:
+    """View (..., K) as (M, K) without copying when the rows are uniformly strided."""
+    if x.dim() == 2:
+        return x if x.stride(1) == 1 else x.contiguous()
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    try:
+        return x.view(-1, x.shape[-1])
+    except RuntimeError:
+        return x.reshape(-1, x.shape[-1])
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = _lib.ACT_NONE,
+           residual: Optional[Tensor] = None, pre_out: Optional[Tensor] = None,
+           out: Optional[Tensor] = None) -> Tensor:
+    """act(x @ w.T + bias) + residual   (vy_linear_fwd)."""
+    _need_gpu(x, w, bias, residual)
+    x2 = _rows(x)
+    M, K = x2.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and w.stride(1) == 1
+    r2 = _rows(residual) if residual is not None else None
+    if out is None:
+        # row stride padded to 8 elements so every row is 16-byte aligned (N = vocab is odd)
+        ldy = (N + 7) // 8 * 8
+        buf = torch.empty((M, ldy), dtype=x.dtype, device=x.device)
+        y2 = buf[:, :N]
+        ret = buf.view(*x.shape[:-1], ldy)[..., :N]
+    else:
+        y2 = _rows(out)
+        ret = out
+    p2 = _rows(pre_out) if pre_out is not None else None
+    if p2 is not None:
+        assert p2.stride(0) == y2.stride(0)
+    call("vy_linear_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
+         _ptr(r2), r2.stride(0) if r2 is not None else 0, y2.data_ptr(), y2.stride(0), _ptr(p2),
+         M, N, K, act, dtype_code(x.dtype), _stream())
+    return ret
+
+
+def qkv_rope(x: Tensor, w_packed: Tensor, b_packed: Optional[Tensor], h: int, hk: int, dh: int,
+             cos: Optional[Tensor], sin: Optional[Tensor], pos0: int,
+             q: Tensor, k: Tensor, v: Tensor) -> None:
+    """Fused projection + RoPE + head split; q/k/v are (B, heads, L, dh) *views* that are written
+    in place (k/v may be slices of a static KV cache).  (vy_qkv_rope_fwd)"""
+    _need_gpu(x, w_packed, q, k, v)
+    B, L, K = x.shape
+    x2 = _rows(x)
+    for t in (q, k, v):
+        assert t.stride(3) == 1
+    call("vy_qkv_rope_fwd", x2.data_ptr(), x2.stride(0), w_packed.data_ptr(), w_packed.stride(0),
+         _ptr(b_packed), _ptr(cos), _ptr(sin), pos0,
+         q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
+         k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
+         B, L, K, h, hk, dh, dtype_code(x.dtype), _stream())
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, *, causal: bool = False, start_pos: int = 0,
+              keypad: Optional[Tensor] = None, addmask: Optional[Tensor] = None,
+              scale: Optional[float] = None, lse: Optional[Tensor] = None,
+              out: Optional[Tensor] = None) -> Tensor:
+    """q (B,h,L,dh), k/v (B,hk,S,dh) -> (B, L, h*dh).  (vy_attn_fwd)"""
+    _need_gpu(q, k, v, keypad, addmask)
+    B, h, L, dh = q.shape
+    hk, S = k.shape[1], k.shape[2]
+    if out is None:
+        out = torch.empty((B, L, h * dh), dtype=q.dtype, device=q.device)
+    kind = 0
+    if causal:
+        kind |= _lib.MASK_CAUSAL
+    if keypad is not None:
+        assert keypad.dtype == torch.uint8 and keypad.shape == (B, S) and keypad.stride(1) == 1
+        kind |= _lib.MASK_KEYPAD
+    am_sb = am_sl = 0
+    if addmask is not None:
+        assert addmask.dtype == torch.float32 and addmask.dim() == 4 and addmask.stride(3) == 1
+        assert addmask.shape[3] == S
+        kind |= _lib.MASK_ADDITIVE
+        am_sb = addmask.stride(0) if addmask.shape[0] > 1 else 0
+        am_sl = addmask.stride(2) if addmask.shape[2] > 1 else 0
+    if scale is None:
+        scale = 1.0 / math.sqrt(dh)
+    call("vy_attn_fwd", q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
+         k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
+         out.data_ptr(), out.stride(0), out.stride(1), _ptr(lse), kind, start_pos,
+         _ptr(keypad), keypad.stride(0) if keypad is not None else 0,
+         _ptr(addmask), am_sb, am_sl, B, h, hk, L, S, dh, float(scale), dtype_code(q.dtype), _stream())
+    return out
+
+
+def attention_decode(q: Tensor, k: Tensor, v: Tensor, S: int, scale: Optional[float] = None) -> Tensor:
+    """q (B,h,1,dh) against cache k/v (B,hk,>=S,dh): attends keys [0,S).  (vy_attn_decode)"""
+    _need_gpu(q, k, v)
+    B, h, _, dh = q.shape
+    hk = k.shape[1]
+    out = torch.empty((B, 1, h * dh), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(dh)
+    call("vy_attn_decode", q.data_ptr(), q.stride(0), q.stride(1),
+         k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
+         out.data_ptr(), out.stride(0), B, h, hk, S, dh, float(scale), dtype_code(q.dtype), _stream())
+    return out
+
+
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float,
+              save_stats: bool = False) -> Tuple[Tensor, Optional[Tensor], Optional[Tensor]]:
+    _need_gpu(x, gamma, beta)
+    x2 = _rows(x)
+    M, N = x2.shape
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    call("vy_layernorm_fwd", x2.data_ptr(), x2.stride(0), gamma.data_ptr(), beta.data_ptr(),
+         y.data_ptr(), y.stride(0), _ptr(mean), _ptr(rstd), M, N, float(eps), dtype_code(x.dtype), _stream())
+    return y.view(x.shape), mean, rstd
+
+
+def rope_(x: Tensor, cos: Tensor, sin: Tensor, pos0: int = 0, inverse: bool = False) -> Tensor:
+    """In-place rotary embedding on (B, heads, L, dh).  (vy_rope_fwd)"""
+    _need_gpu(x, cos, sin)
+    B, heads, L, dh = x.shape
+    assert x.stride(3) == 1
+    call("vy_rope_fwd", x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), cos.data_ptr(),
+         sin.data_ptr(), pos0, B, heads, L, dh, 1 if inverse else 0, dtype_code(x.dtype), _stream())
+    return x
+
+
+def rope_tables(head_dim: int, max_pos: int, device) -> Tuple[Tensor, Tensor]:
+    """fp32 cos/sin of the reference's angle table (VyomAI/layers/positional_embeddings.py:
+    127-137, 173-175), half width (the reference concatenates the angles with themselves).
+    Evaluated on the host in fp32 exactly like the reference, then uploaded once."""
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    t = torch.arange(max_pos).type_as(inv_freq)
+    ang = torch.einsum("i,j->ij", t, inv_freq)
+    return ang.cos().contiguous().to(device), ang.sin().contiguous().to(device)
