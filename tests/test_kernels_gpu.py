@@ -223,4 +223,6 @@ def test_rope_standalone_and_inverse(dtype):
     # the standalone kernel mirrors the reference's per-op rounding
     check(y, want, 1e-6 if dtype == torch.float32 else 1e-2, 0, "rope")
     back = ops.rope_(y.clone(), cos, sin, pos0, inverse=True)
-    check(back, x, 3e-2 if dtype == torch.bfloat16 else 1e-6, 0, "rope inverse round trip")
+    # two roundings per direction in bf16: allow 3 ulps
+    check(back, x, 1e-2 if dtype == torch.bfloat16 else 1e-6, 1.2e-2 if dtype == torch.bfloat16 else 0,
+          "rope inverse round trip")

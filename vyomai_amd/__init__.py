@@ -1,0 +1,12 @@
+"""vyomai_amd -- MI355X-native implementation of VyomAI's transformer hot path.
+
+Same public names as the reference package (VyomAI/__init__.py:1-12) for everything on that
+path; the math runs in hand-written gfx950 HIP kernels behind the C ABI in include/vyom_hip.h.
+"""
+from .utils import EncoderConfig  # noqa: F401
+from .layers.kv_cache import DynamicCache, StaticCache, StaticCacheOne, DynamicCacheOne  # noqa: F401
+from .models.encoder import EncoderModel, EncoderForMaskedLM  # noqa: F401
+from .models.decoder import DecoderModel  # noqa: F401
+from .models.vision_encoder import Vit  # noqa: F401
+from .models.multimodel import VisionLanguageModel  # noqa: F401
+from .generation_utils import generate, generate_multimodel  # noqa: F401

@@ -1,0 +1,120 @@
+"""The three fused groups of a VyomAI layer, forward and backward, on the HIP kernels:
+
+  self_attention_block      QKV+RoPE -> flash attention -> out-proj + residual -> LayerNorm
+  linear_residual_layernorm AttentionSelfOutput on its own
+  ffn_block                 GEMM+GELU -> GEMM + residual -> LayerNorm
+
+The grouping follows the reference author's own fused ops (Examples/vyom-ai-decoder-fused.ipynb
+cells 2-7: LinearRms, FFNGeLU, ScaledDotProductAttention, RotaryEmbeddingFunction).  Inference
+calls go straight to the forward kernels; when gradients are required the same kernels run inside
+torch.autograd.Function wrappers whose backward is the vy_*_bwd / dgrad / wgrad entry points.
+PyTorch autograd is only the tape; no PyTorch math runs in either direction.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import VyomHipError
+from .layers.mask import AttnMask
+from .layers.positional_embeddings import resolve_freqs
+
+
+def _shadow(param: Optional[torch.Tensor], dtype: torch.dtype) -> Optional[torch.Tensor]:
+    from .layers.attention import _shadow as s
+    return s(param, dtype)
+
+
+def _wants_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+# ------------------------------------------------------------------------------------------
+# forward-only (inference) paths
+# ------------------------------------------------------------------------------------------
+
+
+def linear_residual_layernorm(x, residual, w, b, ln_w, ln_b, eps):
+    if _wants_grad(x, residual, w, b, ln_w, ln_b):
+        from .autograd_train import LinearResidualLayerNormFn
+        return LinearResidualLayerNormFn.apply(x, residual, w, b, ln_w, ln_b, eps)
+    dt = x.dtype
+    s = ops.linear(x, _shadow(w, dt), _shadow(b, dt), residual=residual)
+    y, _, _ = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps)
+    return y
+
+
+def ffn_block(x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act):
+    if _wants_grad(x, residual, w1, b1, w2, b2, ln_w, ln_b):
+        from .autograd_train import FfnBlockFn
+        return FfnBlockFn.apply(x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act)
+    dt = x.dtype
+    hmid = ops.linear(x, _shadow(w1, dt), _shadow(b1, dt), act=act)
+    s = ops.linear(hmid, _shadow(w2, dt), _shadow(b2, dt), residual=residual)
+    y, _, _ = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps)
+    return y
+
+
+def _mask_args(mask, B, L, S, device):
+    """-> dict(causal, start_pos, keypad, addmask) for ops.attention."""
+    if mask is None:
+        return dict(causal=False, start_pos=0, keypad=None, addmask=None)
+    if isinstance(mask, AttnMask):
+        kp = mask.keypad
+        if kp is not None:
+            if kp.shape[-1] < S:
+                raise ValueError(f"attention mask covers {kp.shape[-1]} keys, attention sees {S}")
+            kp = kp[:, :S]
+            if kp.device != device:
+                kp = kp.to(device)
+            if not kp.is_contiguous() and kp.stride(1) != 1:
+                kp = kp.contiguous()
+        return dict(causal=mask.causal, start_pos=mask.start_pos, keypad=kp, addmask=None)
+    # dense additive float mask, the reference's interface: (B|1, 1, L|1, S)
+    if mask.dim() != 4 or mask.shape[-1] != S:
+        raise ValueError(f"additive attention_mask must be (B,1,L,S) with S={S}, got {tuple(mask.shape)}")
+    am = mask.to(device=device, dtype=torch.float32)
+    if am.stride(3) != 1:
+        am = am.contiguous()
+    return dict(causal=False, start_pos=0, keypad=None, addmask=am)
+
+
+def self_attention_block(mod, x, attention_mask, freqs, cache, cache_index, start_pos):
+    """mod: a vyomai_amd.layers.attention._SelfAttentionBase.  Returns LN(out(attn(x)) + x)."""
+    B, L, _ = x.shape
+    h, hk, dh = mod.num_attention_heads, mod.num_key_value_heads, mod.head_dim
+    dt, dev = x.dtype, x.device
+    w, b = mod._packed()
+    aso = mod.out
+    train = _wants_grad(x, w, b, aso.dense.weight)
+    if train:
+        if cache is not None:
+            raise VyomHipError("KV caching is an inference feature; call under torch.no_grad()")
+        from .autograd_train import SelfAttentionFn
+        o = SelfAttentionFn.apply(x, w, b, mod, attention_mask, freqs, start_pos)
+        return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
+                                         aso.layernorm.bias, aso.layernorm.eps)
+    cos, sin, pos0 = resolve_freqs(freqs, dev)
+    q = torch.empty((B, h, L, dh), dtype=dt, device=dev)
+    if cache is not None:
+        if cache_index is None:
+            kw, vw = cache.reserve(B, hk, L, dh, start_pos, dt, dev)
+        else:
+            kw, vw = cache.reserve(cache_index, B, hk, L, dh, start_pos, dt, dev)
+    else:
+        kw = torch.empty((B, hk, L, dh), dtype=dt, device=dev)
+        vw = torch.empty_like(kw)
+    ops.qkv_rope(x, _shadow(w, dt), _shadow(b, dt), h, hk, dh, cos, sin, pos0, q, kw, vw)
+    if cache is not None:
+        k_all, v_all = cache.commit() if cache_index is None else cache.commit(cache_index)
+    else:
+        k_all, v_all = kw, vw
+    S = k_all.shape[2]
+    if L == 1 and attention_mask is None:
+        o = ops.attention_decode(q, k_all, v_all, S)
+    else:
+        o = ops.attention(q, k_all, v_all, **_mask_args(attention_mask, B, L, S, dev))
+    return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
+                                     aso.layernorm.bias, aso.layernorm.eps)

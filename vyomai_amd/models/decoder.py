@@ -1,0 +1,174 @@
+"""GPT-style decoder with the reference's API (VyomAI/models/decoder.py): DecoderAttention /
+DecoderAttentionGqa that thread ``kv_cache`` through forward, DecoderLayer, LMHead, DecoderModel
+with create_mask_for_decoder and the batched greedy ``generate``.  All layer math runs in the
+HIP kernels; this file is host-side orchestration."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from ..layers.attention import _SelfAttentionBase
+from ..layers.ffn import FeedForward
+from ..layers.kv_cache import DynamicCacheOne, StaticCacheOne
+from ..layers.mask import AttnMask
+from .common import LMHead, PositionMixin
+
+
+@dataclass
+class DecoderOutput(object):
+    logits: torch.Tensor
+
+
+@dataclass
+class CLMOutput(object):
+    hidden_state: torch.Tensor
+    logits: torch.Tensor
+    kv_cache: List[torch.FloatTensor] = None
+
+
+class DecoderAttention(_SelfAttentionBase):
+    """forward(hidden_state, attention_mask, freqs, use_cache, kv_cache, start_pos)
+    -> (hidden_state, kv_cache).  Reference :44-113."""
+
+    def __init__(self, config, layer_idx: int) -> None:
+        super().__init__()
+        self._setup(config, layer_idx, None, fused_qkv=False)
+
+    def forward(self, hidden_state, attention_mask, freqs=None, use_cache: Optional[bool] = False,
+                kv_cache=None, start_pos: Optional[int] = 0):
+        if use_cache and kv_cache is None:
+            raise ValueError("you need to pass kv_cache")
+        out = self._attend(hidden_state, attention_mask, freqs, kv_cache if use_cache else None,
+                           self.layer_idx, start_pos)
+        return out, kv_cache
+
+
+class DecoderAttentionGqa(_SelfAttentionBase):
+    """Reference :116-201 (K/V projections of num_key_value_heads heads, default 4)."""
+
+    def __init__(self, config, layer_idx: int) -> None:
+        super().__init__()
+        self._setup(config, layer_idx, getattr(config, "num_key_value_heads", 4), fused_qkv=False)
+
+    def forward(self, hidden_state, attention_mask, freqs=None, use_cache: Optional[bool] = False,
+                kv_cache=None, start_pos: Optional[int] = 0):
+        if use_cache and kv_cache is None:
+            raise ValueError("you need to pass kv_cache")
+        out = self._attend(hidden_state, attention_mask, freqs, kv_cache if use_cache else None,
+                           self.layer_idx, start_pos)
+        return out, kv_cache
+
+
+class DecoderLayer(nn.Module):
+    """a = attention(h); return feed_forward(a, h): the FFN residual is the LAYER INPUT, as in the
+    reference (:241-250)."""
+
+    def __init__(self, config, layer_idx: int, attention_type: Optional[str] = None) -> None:
+        super().__init__()
+        self.attention = (DecoderAttentionGqa(config, layer_idx=layer_idx) if attention_type == "gqa"
+                          else DecoderAttention(config, layer_idx=layer_idx))
+        if attention_type == "gqa" and layer_idx == 0:
+            print("Decoder Using GQA Attention")
+        self.feed_forward = FeedForward(config)
+        self.layer_idx = layer_idx
+
+    def forward(self, hidden_state, attention_mask, freqs=None, use_cache: Optional[bool] = False,
+                kv_cache=None, start_pos: Optional[int] = 0):
+        out, kv_cache = self.attention(hidden_state=hidden_state, attention_mask=attention_mask, freqs=freqs,
+                                       use_cache=use_cache, kv_cache=kv_cache, start_pos=start_pos)
+        return self.feed_forward(out, hidden_state), kv_cache
+
+
+class DecoderModel(nn.Module, PositionMixin):
+    """Reference :278-514."""
+
+    def __init__(self, config, pos_embedding_type: Optional[str] = "absolute",
+                 attention_type: Optional[str] = None) -> None:
+        super().__init__()
+        self.is_gqa = attention_type == "gqa"
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size,
+                                            padding_idx=getattr(config, "pad_token_id", None))
+        self._init_positions(config, pos_embedding_type, "Decoder")
+        self.all_layer = nn.ModuleList(
+            [DecoderLayer(config, i, attention_type) for i in range(config.num_hidden_layers)])
+        self.lm_head = LMHead(config=config)
+        self.config = config
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                use_cache: Optional[bool] = False, kv_cache=None, start_pos: Optional[int] = 0) -> CLMOutput:
+        _bsz, seqlen = input_ids.shape
+        hidden_state = self.word_embeddings(input_ids)
+        hidden_state, freqs = self._positions(hidden_state, start_pos, seqlen)
+        mask = None
+        if seqlen > 1:
+            mask = self.create_mask_for_decoder(input_ids=input_ids, attention_mask=attention_mask,
+                                                start_pos=start_pos)
+        for layer in self.all_layer:
+            hidden_state, kv_cache = layer(hidden_state, mask, freqs=freqs, use_cache=use_cache,
+                                           kv_cache=kv_cache, start_pos=start_pos)
+        logits = self.lm_head(hidden_state)
+        return CLMOutput(hidden_state=hidden_state, logits=logits, kv_cache=kv_cache)
+
+    def create_mask_for_decoder(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                                start_pos: Optional[int] = 0) -> AttnMask:
+        """The reference (:376-419) returns the dense (B,1,L,start+L) 0/1 product of the causal
+        and padding masks, which forward() inverts to an additive tensor.  Here the same
+        information is returned as a descriptor the attention kernel evaluates in registers;
+        ``.dense()`` rebuilds the reference's additive tensor."""
+        _, seq_length = input_ids.shape
+        return AttnMask.from_padding(attention_mask, causal=True, start_pos=start_pos, query_len=seq_length)
+
+    @classmethod
+    def from_config(cls, config, pos_embedding_type: Optional[str] = "absolute",
+                    attention_type: Optional[str] = None) -> nn.Module:
+        return cls(config, pos_embedding_type, attention_type)
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, max_len: int = 5,
+                 temperature: float = 1.0, use_cache: bool = True, do_sample: bool = False,
+                 use_static_cache: bool = False) -> torch.Tensor:
+        """Batched generation loop of the reference (:430-514): fills a (B, prompt+max_len) token
+        matrix, forcing prompt tokens while a row is still inside its prompt; greedy = top-1 of the
+        last position.  The end-of-sequence bookkeeping stays on the device and is checked with
+        one scalar read per token."""
+        device = input_ids.device
+        bsz, prompt_len = input_ids.shape
+        total = max_len + prompt_len
+        pad_id = getattr(self.config, "pad_token_id", 1)
+        tokens = torch.full((bsz, total), pad_id, dtype=torch.long, device=device)
+        tokens[:, :prompt_len] = input_ids
+        kv_cache = None
+        if use_cache:
+            if use_static_cache:
+                kv_cache = StaticCacheOne(self.config, max_cache_len=total, batch_size=bsz,
+                                          dtype=self.word_embeddings.weight.dtype)
+            else:
+                kv_cache = DynamicCacheOne(self.config)
+        prev_pos = 0
+        eos_reached = torch.zeros(bsz, dtype=torch.bool, device=device)
+        input_text_mask = tokens != pad_id
+        stop_tokens = torch.tensor(getattr(self.config, "eos_token_id", 2), device=device)
+        for cur_pos in range(prompt_len, total):
+            outputs = self.forward(input_ids=tokens[:, prev_pos:cur_pos], attention_mask=attention_mask,
+                                   use_cache=use_cache, kv_cache=kv_cache, start_pos=prev_pos)
+            kv_cache = outputs.kv_cache
+            next_token_logits = outputs.logits[:, -1] / temperature
+            if do_sample:
+                # the reference samples from the raw logits (:491-492); kept
+                next_token = torch.multinomial(next_token_logits.float(), num_samples=1)
+            else:
+                _, next_token = torch.topk(next_token_logits, k=1, dim=-1)
+            next_token = next_token.reshape(-1)
+            next_token = torch.where(input_text_mask[:, cur_pos], tokens[:, cur_pos], next_token)
+            tokens[:, cur_pos] = next_token
+            eos_reached |= (~input_text_mask[:, cur_pos]) & torch.isin(next_token, stop_tokens)
+            if use_cache:
+                prev_pos = cur_pos
+            attention_mask = torch.cat(
+                [attention_mask, torch.ones((bsz, 1), device=device, dtype=attention_mask.dtype)], dim=-1)
+            if bool(eos_reached.all()):
+                break
+        return tokens
