@@ -1,0 +1,137 @@
+"""Backward kernels vs torch autograd on the CPU oracle functions (fp64/fp32), bf16 tolerances."""
+import math
+
+import pytest
+import torch
+
+from oracle import vyom_oracle as O
+from tests.test_kernels_gpu import check, rnd, _dense_mask
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _ops():
+    from vyomai_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 768, 768), (4096, 3072, 768), (777, 768, 3072), (64, 2304, 768)])
+def test_wgrad(M, N, K):
+    ops = _ops()
+    dy, x = rnd(M, N, seed=1).to(BF), rnd(M, K, seed=2).to(BF)
+    dw = torch.full((N, K), 7.0, dtype=torch.float32, device=DEV)
+    db = torch.full((N,), 7.0, dtype=torch.float32, device=DEV)
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw, db, accumulate=False)
+    want = dy.double().t() @ x.double()
+    tol = 2e-3 * math.sqrt(M)
+    check(dw, want, tol, 1e-3, "dW")
+    check(db, dy.double().sum(0), tol, 1e-3, "db")
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw, db, accumulate=True)
+    check(dw, 2 * want, 2 * tol, 1e-3, "dW accumulate")
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 768, 3072, 1), (1024, 768, 768, 0), (51, 3072, 768, 0)])
+def test_dgrad(M, N, K, act):
+    """dX[M,K] = dY[M,N] @ W[N,K] (* gelu'(pre)) (+ add)."""
+    ops = _ops()
+    dy = rnd(M, N, seed=1).to(BF)
+    w = (rnd(N, K, seed=2) / math.sqrt(N)).to(BF)
+    pre = rnd(M, K, seed=3).to(BF)
+    add = rnd(M, K, seed=4).to(BF)
+    want = dy.double() @ w.double()
+    if act:
+        p = pre.double().requires_grad_(True)
+        O.gelu_erf(p).sum().backward()
+        want = want * p.grad
+    want = want + add.double()
+    wt = ops.transpose(w.to(DEV))
+    check(wt, w.t(), 0, 0, "transpose")
+    got = ops.linear_dgrad(dy.to(DEV), wt, pre.to(DEV) if act else None, act, add.to(DEV))
+    check(got, want, 4e-2, 1e-2, "dgrad")
+
+
+@pytest.mark.parametrize("M,N", [(1000, 768), (64, 64), (5000, 768)])
+def test_layernorm_bwd(M, N):
+    ops = _ops()
+    x = (rnd(M, N, seed=1) * 2 + 0.3).to(BF)
+    g = (1 + 0.1 * rnd(N, seed=2)).to(BF)
+    b = (0.1 * rnd(N, seed=3)).to(BF)
+    dy = rnd(M, N, seed=4).to(BF)
+    xd, gd, bd = x.double().requires_grad_(True), g.double().requires_grad_(True), b.double().requires_grad_(True)
+    (torch.nn.functional.layer_norm(xd, (N,), gd, bd, 1e-5) * dy.double()).sum().backward()
+    y, mean, rstd = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, save_stats=True)
+    dg = torch.zeros(N, dtype=torch.float32, device=DEV)
+    dbt = torch.zeros(N, dtype=torch.float32, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), g.to(DEV), mean, rstd, dg, dbt, accumulate=False)
+    check(dx, xd.grad, 3e-2, 1e-2, "dx")
+    check(dg, gd.grad, 2e-3 * math.sqrt(M), 1e-3, "dgamma")
+    check(dbt, bd.grad, 2e-3 * math.sqrt(M), 1e-3, "dbeta")
+
+
+BWD_CASES = [
+    # B, h, hk, L, S, causal, start, keypad
+    (2, 4, 4, 128, 128, True, 0, False),
+    (2, 4, 2, 200, 200, True, 0, False),
+    (1, 2, 2, 96, 96, False, 0, False),
+    (2, 4, 2, 130, 130, True, 0, True),
+    (2, 3, 1, 70, 70, False, 0, True),
+    (2, 12, 12, 512, 512, True, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_attention_bwd(case):
+    ops = _ops()
+    B, h, hk, L, S, causal, start, use_kp = case
+    dh = 64
+    q = rnd(B, h, L, dh, seed=1).to(BF)
+    k = rnd(B, hk, S, dh, seed=2).to(BF)
+    v = rnd(B, hk, S, dh, seed=3).to(BF)
+    do = rnd(B, L, h * dh, seed=4).to(BF)
+    keypad = None
+    if use_kp:
+        keypad = torch.ones(B, S, dtype=torch.uint8)
+        keypad[0, S - S // 3:] = 0
+        if B > 1:
+            keypad[1, S - 7:] = 0
+    mask = _dense_mask(B, L, S, causal, start, keypad, None)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = qd @ O.repeat_kv(kd, h // hk).transpose(-1, -2) / math.sqrt(dh) + mask.double()
+    out_ref = O.merge_heads(torch.softmax(s, -1) @ O.repeat_kv(vd, h // hk))
+    (out_ref * do.double()).sum().backward()
+    qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
+    lse = torch.zeros(B, h, L, dtype=torch.float32, device=DEV)
+    out = ops.attention(qg, kg, vg, causal=causal, start_pos=start,
+                        keypad=keypad.to(DEV) if keypad is not None else None, lse=lse)
+    # dq/dk/dv written into one packed (B, L, (h+2hk)*dh) buffer, the layout the QKV dgrad consumes
+    W = (h + 2 * hk) * dh
+    packed = torch.zeros(B, max(L, S), W, dtype=BF, device=DEV)
+    dq = packed[:, :L, : h * dh].view(B, L, h, dh).permute(0, 2, 1, 3)
+    dk = packed[:, :S, h * dh:(h + hk) * dh].view(B, S, hk, dh).permute(0, 2, 1, 3)
+    dv = packed[:, :S, (h + hk) * dh:].view(B, S, hk, dh).permute(0, 2, 1, 3)
+    ops.attention_bwd(qg, kg, vg, out, do.to(DEV), lse, dq, dk, dv, causal=causal, start_pos=start,
+                      keypad=keypad.to(DEV) if keypad is not None else None)
+    check(out, out_ref, 2e-2, 2e-2, "fwd out")
+    check(dq, qd.grad, 4e-2, 3e-2, "dq")
+    check(dk, kd.grad, 4e-2, 3e-2, "dk")
+    check(dv, vd.grad, 4e-2, 3e-2, "dv")
+
+
+def test_adamw_matches_torch():
+    ops = _ops()
+    n = 100003
+    p0, g = rnd(n, seed=1), rnd(n, seed=2)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p = p0.clone().to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    pb = torch.zeros(n, dtype=BF, device=DEV)
+    for step in range(1, 4):
+        pt.grad = g.clone() * step
+        opt.step()
+        ops.adamw_step(p, (g * step).to(DEV), m, v, pb, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    check(p, pt.detach(), 1e-6, 1e-5, "adamw")
+    check(pb, pt.detach().to(BF), 1e-2, 1e-2, "adamw bf16 shadow")

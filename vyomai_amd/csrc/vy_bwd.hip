@@ -1,13 +1,562 @@
-// placeholder until the backward kernels land (same translation unit will hold them)
+// Backward kernels of the block (bf16 storage, fp32 accumulation):
+//
+//   vy_linear_wgrad  dW[N,K] += dY[M,N]^T . X[M,K]   "TN" GEMM: the contraction index m is the
+//                    slow index of BOTH operands, so both MFMA fragments are transposing LDS reads
+//                    (ds_read_b64_tr_b16) of row-major [m][n] / [m][k] tiles staged by LDS-DMA.
+//                    M is split over workgroups (few (n,k) tiles exist at d=768) and partial tiles
+//                    are summed with fp32 atomics shaped as two 128-B row segments per wave
+//                    instruction.  db = column sums of dY (separate streaming kernel).
+//   vy_attn_bwd      flash attention backward as two MFMA kernels without atomics:
+//                      dq kernel:   per 128 query rows, sweep keys (S^T, dP^T, dQ^T products);
+//                      dkdv kernel: per 128 keys of one kv head, sweep the n_rep query heads and
+//                                   query tiles (S, dP, dV^T, dK^T products), GQA sum in registers.
+//                    P is recomputed from the forward's log-sum-exp; the row constants -lse/scale
+//                    and -delta are the initial values of the S and dP accumulators.
+//
+// The backward formulas are the ones autograd derives for the reference modules; the attention
+// one is spelled out by the reference author in Examples/vyom-ai-decoder-fused.ipynb cell 7
+// (dS = P o (dP - rowsum(dO o O))).
 #include "vy_common.h"
-extern "C" int vy_linear_wgrad(const void*, int64_t, const void*, int64_t, float*, int64_t, float*, float,
-                               int64_t, int64_t, int64_t, int, void*) {
-  VY_FAIL(VY_ERR_UNSUPPORTED, "vy_linear_wgrad: not built yet");
+#include <float.h>
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
-extern "C" int vy_attn_bwd(const void*, int64_t, int64_t, int64_t, const void*, int64_t, int64_t, int64_t,
-                           const void*, int64_t, int64_t, int64_t, const void*, const void*, int64_t, int64_t,
-                           const float*, float*, void*, int64_t, int64_t, int64_t, void*, int64_t, int64_t,
-                           int64_t, void*, int64_t, int64_t, int64_t, int, int64_t, const uint8_t*, int64_t,
-                           int64_t, int, int, int64_t, int64_t, int, float, int, void*) {
-  VY_FAIL(VY_ERR_UNSUPPORTED, "vy_attn_bwd: not built yet");
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
+  // two transposing reads 8 rows apart -> the 8 k-elements of one 32x32x16 operand
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(base + 8 * row_bytes));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: dW[n,k] += sum_m dY[m,n] X[m,k]
+// tile 128(n) x 128(k), 64 rows of m per stage, 4 waves 2x2 of 64x64, split over M
+// ------------------------------------------------------------------------------------------
+constexpr int WROW = 256;  // bytes per LDS row (128 bf16)
+
+__global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(
+    const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
+    float* __restrict__ dW, int64_t lddw, int M, int N, int K, int tiles_k, int tiles_nk, int m_chunk) {
+  constexpr int STAGE = 2 * 64 * WROW;  // dY tile + X tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wg / tiles_nk, t2 = wg - split * tiles_nk;
+  const int tile_n = t2 / tiles_k, tile_k = t2 - tile_n * tiles_k;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int m_begin = split * m_chunk;
+  const int m_end = min(M, m_begin + m_chunk);
+  if (m_begin >= m_end) return;
+  const int nst = (m_end - m_begin + 63) / 64;
+
+  // LDS-DMA geometry: 16 pieces of 1 KiB (4 rows of 256 B) per tile, 4 per wave per operand
+  int ld_row[4], ld_off[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int P = (wave * 4 + t) * 1024 + lane * 16;
+    const int row = P / WROW, off = P % WROW;
+    ld_row[t] = row;
+    ld_off[t] = (off ^ ((row & 3) << 6)) >> 1;  // element offset, 64-B swizzle on the source side
+  }
+  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
+  auto stage = [&](int s, int buf) {
+    const int mb = m_begin + s * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int m = mb + ld_row[t];
+      const bool mv = m < m_end;
+      const bf16* a = (mv && n0 + ld_off[t] < N) ? dY + (int64_t)m * lddy + n0 + ld_off[t] : zero;
+      const bf16* b = (mv && k0 + ld_off[t] < K) ? X + (int64_t)m * ldx + k0 + ld_off[t] : zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)a,
+                                       (VY_LDS void*)(smem + buf * STAGE + (wave * 4 + t) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)b,
+                                       (VY_LDS void*)(smem + buf * STAGE + 64 * WROW + (wave * 4 + t) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int li = lane & 15, g16 = (lane >> 4) & 1, fh = lane >> 5;
+  const int tr_row = 4 * fh + (li >> 2);                  // + 16*s (second read +8)
+  const int tr_sw = ((li >> 2) & 3) << 6;                 // (row & 3) << 6
+  const int a_off = (2 * (wn * 64 + 16 * g16 + 4 * (li & 3)));  // + 64*i, then ^ tr_sw
+  const int b_off = (2 * (wk * 64 + 16 * g16 + 4 * (li & 3)));
+
+  stage(0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nst) stage(s + 1, cur ^ 1);
+    const char* ab = smem + cur * STAGE;
+    const char* bb = ab + 64 * WROW;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = tr_pair(ab + (16 * ks + tr_row) * WROW + ((a_off + 64 * i) ^ tr_sw), WROW);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bfr[j] = tr_pair(bb + (16 * ks + tr_row) * WROW + ((b_off + 64 * j) ^ tr_sw), WROW);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  const int fr = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wk * 64 + 32 * j + fr;
+      if (k >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (n < N) atomicAdd(dW + (int64_t)n * lddw + k, acc[i][j][r]);
+      }
+    }
+}
+
+// db[n] += sum_m dY[m,n]: block = 64 lanes x 8 columns, 256 rows per block
+__global__ __launch_bounds__(64) void colsum_bf16_kernel(const bf16* __restrict__ dY, int64_t lddy,
+                                                         float* __restrict__ db, int M, int N) {
+  const int c0 = (blockIdx.x * 64 + threadIdx.x) * 8;
+  if (c0 >= N) return;
+  const int m0 = blockIdx.y * 256, m1 = min(M, m0 + 256);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int m = m0; m < m1; ++m) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(dY + (int64_t)m * lddy + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(db + c0 + e, s[e]);
+}
+
+// ------------------------------------------------------------------------------------------
+// attention backward
+// ------------------------------------------------------------------------------------------
+struct BwdParams {
+  const bf16* q; int64_t q_sb, q_sh, q_sl;
+  const bf16* k; int64_t k_sb, k_sh, k_sl;
+  const bf16* v; int64_t v_sb, v_sh, v_sl;
+  const bf16* o; const bf16* dout; int64_t o_sb, o_sl;
+  const float* lse; float* delta;
+  bf16* dq; int64_t dq_sb, dq_sh, dq_sl;
+  bf16* dk; int64_t dk_sb, dk_sh, dk_sl;
+  bf16* dv; int64_t dv_sb, dv_sh, dv_sl;
+  int mask_kind; int start_pos;
+  const uint8_t* keypad; int64_t kp_sb;
+  int B, h, hk, L, S;
+  float scale;
+};
+
+// delta[b,h,q] = sum_d dO[b,q,h*dh+d] * O[b,q,h*dh+d]; one wave per (b,q) row, dh = 64
+__global__ __launch_bounds__(256) void attn_delta_kernel(BwdParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)p.B * p.L) return;
+  const int b = (int)(row / p.L), qi = (int)(row - (int64_t)b * p.L);
+  const bf16* o = p.o + (int64_t)b * p.o_sb + (int64_t)qi * p.o_sl;
+  const bf16* g = p.dout + (int64_t)b * p.o_sb + (int64_t)qi * p.o_sl;
+  const int nch = p.h * 8;  // 16-byte chunks per row (dh = 64 -> 8 per head)
+  for (int c = lane; c < ((nch + 63) / 64) * 64; c += 64) {
+    float s = 0.f;
+    if (c < nch) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + c * 8);
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(g + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)d[e];
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (c < nch && (c & 7) == 0) p.delta[((int64_t)b * p.h + (c >> 3)) * p.L + qi] = s;
+  }
+}
+
+// chunk swizzle of a 128-B-row LDS image that is read BOTH by rows (ds_read_b128) and transposed
+// (ds_read_b64_tr_b16): conflict-free for both ("dual-use image")
+__device__ __forceinline__ int dual_sw(int row) {
+  const int v = (row >> 1) & 7;
+  return ((v & 1) << 2) | (v >> 1);
+}
+
+// ---- dq kernel: forward structure, no online softmax --------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
+  constexpr int DH = 64, RB = 128, TILE = 64 * RB;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // K0 K1 V0 V1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (p.L + 127) / 128;
+  const int qb = nqb - 1 - (int)blockIdx.x;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int kvh = head / (p.h / p.hk);
+  const int q0 = qb * 128;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int qi = q0 + wave * 32 + fr;
+  const int qrow = qi < p.L ? qi : p.L - 1;
+  const bf16* Q = p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qrow * p.q_sl;
+  const bf16* dO = p.dout + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + head * DH;
+  const bf16* Kb = p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
+  const bf16* Vb = p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+  bf16x8 qf[4], gf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8*>(Q + ks * 16 + fh * 8);
+    gf[ks] = *reinterpret_cast<const bf16x8*>(dO + ks * 16 + fh * 8);
+  }
+  const int64_t stat = ((int64_t)b * p.h + head) * p.L + qrow;
+  const float c = p.scale * LOG2E;
+  const float neg_lse = -p.lse[stat] * LOG2E;  // p = exp2(c*s + neg_lse)
+  const float neg_delta = -p.delta[stat];
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const uint8_t* kp = haskp ? p.keypad + (int64_t)b * p.kp_sb : nullptr;
+
+  int ld_row[2], ld_koff[2], ld_voff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int P = (wave * 2 + t) * 1024 + lane * 16;
+    const int row = P / RB, off = P % RB;
+    ld_row[t] = row;
+    ld_koff[t] = (((off >> 4) ^ dual_sw(row)) << 4) >> 1;   // K: dual-use image
+    ld_voff[t] = (((off >> 4) ^ ((row >> 1) & 7)) << 4) >> 1;  // V: row reads only
+  }
+  auto stage = [&](int tile, int buf) {
+    const int k0 = tile * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int kr = k0 + ld_row[t];
+      kr = kr < p.S ? kr : p.S - 1;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(Kb + (int64_t)kr * p.k_sl + ld_koff[t]),
+                                       (VY_LDS void*)(smem + buf * TILE + (wave * 2 + t) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(Vb + (int64_t)kr * p.v_sl + ld_voff[t]),
+                                       (VY_LDS void*)(smem + (2 + buf) * TILE + (wave * 2 + t) * 1024), 16, 0, 0);
+    }
+  };
+  const int k_sw = dual_sw(fr), v_sw = (fr >> 1) & 7;
+  const int li = lane & 15, g16 = (lane >> 4) & 1;
+  const int t_row = 4 * fh + (li >> 2);
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[n][r] = 0.f;
+
+  int nt = (p.S + 63) / 64;
+  if (causal) nt = min(nt, (min(p.S, p.start_pos + q0 + 128) + 63) / 64);
+  const int wave_first = q0 + wave * 32, wave_last = wave_first + 31;
+
+  stage(0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1, k0 = t * 64;
+    if (t + 1 < nt) stage(t + 1, buf ^ 1);
+    if (!(causal && k0 > p.start_pos + wave_last)) {
+      const char* kb_ = smem + buf * TILE;
+      const char* vb_ = smem + (2 + buf) * TILE;
+      f32x16 st[2], dp[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = neg_delta; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ k_sw) << 4));
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ v_sw) << 4));
+          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+          dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], dp[kb], 0, 0, 0);
+        }
+      }
+      const bool need_mask = haskp || (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first);
+      bf16x8 ds[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pr = exp2f(st[kb][r] * c + neg_lse);
+          if (need_mask) {
+            const int kj = k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (kj >= p.S || (causal && kj > qi + p.start_pos) || (haskp && !kp[kj])) pr = 0.f;
+          }
+          ds[kb][r >> 3][r & 7] = (bf16)(pr * dp[kb][r]);
+        }
+      // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int row = 32 * kb + 16 * s + t_row;
+            const int chunk = 4 * n + 2 * g16 + ((li & 3) >> 1);
+            // rows row and row+8 share dual_sw's low-order behaviour only through (row>>1)&7:
+            const char* a0 = kb_ + row * RB + ((chunk ^ dual_sw(row)) << 4) + 8 * (li & 1);
+            const char* a1 = kb_ + (row + 8) * RB + ((chunk ^ dual_sw(row + 8)) << 4) + 8 * (li & 1);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)a0);
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)a1);
+            union { struct { s16x4 a, b; } s_; bf16x8 v; } u;
+            u.s_.a = lo; u.s_.b = hi;
+            dq[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ds[kb][s], dq[n], 0, 0, 0);
+          }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  if (qi < p.L) {
+    bf16* D = p.dq + (int64_t)b * p.dq_sb + (int64_t)head * p.dq_sh + (int64_t)qi * p.dq_sl;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (bf16)(dq[n][4 * rg + e] * p.scale);
+        *reinterpret_cast<bf16x4*>(D + 32 * n + 8 * rg + 4 * fh) = w;
+      }
+  }
+}
+
+// ---- dk/dv kernel ----------------------------------------------------------------------------
+// workgroup = 128 keys of one (batch, kv head); wave w owns keys [k0+32w, +32) and keeps dK^T and
+// dV^T for them in registers while the workgroup sweeps (query head of the group) x (32-row query
+// tile); Q and dO tiles are staged by LDS-DMA into dual-use images (row + transposed reads).
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(BwdParams p) {
+  constexpr int DH = 64, RB = 128, QT = 32 * RB;  // one 32-row tile = 4 KiB
+  __shared__ __attribute__((aligned(16))) char smem[4 * QT];  // Q0 Q1 dO0 dO1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kblk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  const int n_rep = p.h / p.hk;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int key0 = kblk * 128 + wave * 32;
+  const int kj = key0 + fr;                       // this lane's key (column of S)
+  const int krow = kj < p.S ? kj : p.S - 1;
+  const bf16* Kp = p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh + (int64_t)krow * p.k_sl;
+  const bf16* Vp = p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh + (int64_t)krow * p.v_sl;
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8*>(Kp + ks * 16 + fh * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8*>(Vp + ks * 16 + fh * 8);
+  }
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const bool key_dead = (kj >= p.S) || (haskp && !p.keypad[(int64_t)b * p.kp_sb + krow]);
+  const float c = p.scale * LOG2E;
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[n][r] = 0.f; dv[n][r] = 0.f; }
+
+  // query tiles that can see any key of this block: rows >= block_first_key - start_pos
+  const int nqt = (p.L + 31) / 32;
+  int qt_first = 0;
+  if (causal) {
+    const int first_row = kblk * 128 - p.start_pos;
+    qt_first = first_row > 0 ? first_row / 32 : 0;
+  }
+  const int per_head = nqt > qt_first ? nqt - qt_first : 0;
+  const int total = per_head * n_rep;
+
+  // LDS-DMA: tile = 4 pieces of 1 KiB; wave w loads piece w of the Q tile and of the dO tile
+  const int ldP = wave * 1024 + lane * 16;
+  const int ld_row = ldP / RB, ld_off = ldP % RB;
+  const int ld_eoff = (((ld_off >> 4) ^ dual_sw(ld_row)) << 4) >> 1;
+  auto stage = [&](int it, int buf) {
+    const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
+    const int head = kvh * n_rep + hh;
+    int qr = qt * 32 + ld_row;
+    qr = qr < p.L ? qr : p.L - 1;
+    const bf16* qs = p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qr * p.q_sl + ld_eoff;
+    const bf16* gs = p.dout + (int64_t)b * p.o_sb + (int64_t)qr * p.o_sl + head * DH + ld_eoff;
+    __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)qs, (VY_LDS void*)(smem + buf * QT + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)gs, (VY_LDS void*)(smem + (2 + buf) * QT + wave * 1024), 16, 0, 0);
+  };
+  const int r_sw = dual_sw(fr);
+  const int li = lane & 15, g16 = (lane >> 4) & 1;
+  const int t_row = 4 * fh + (li >> 2);
+
+  if (total > 0) {
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  for (int it = 0; it < total; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < total) stage(it + 1, buf ^ 1);
+    const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
+    const int head = kvh * n_rep + hh;
+    const int qbase = qt * 32;
+    // wave-uniform skip: every key of this wave is above the tile's last row's diagonal
+    if (!(causal && key0 > qbase + 31 + p.start_pos)) {
+      const char* qb_ = smem + buf * QT;
+      const char* gb_ = smem + (2 + buf) * QT;
+      // row constants: register r <-> query row qbase + (r&3) + 8(r>>2) + 4h
+      const float* lse = p.lse + ((int64_t)b * p.h + head) * p.L;
+      const float* dlt = p.delta + ((int64_t)b * p.h + head) * p.L;
+      f32x16 st, dp;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int qi = qbase + 8 * rg + 4 * fh + e;
+          qi = qi < p.L ? qi : p.L - 1;
+          st[4 * rg + e] = -lse[qi] / p.scale;   // S' = S - lse/scale  ->  p = exp2(c * S')
+          dp[4 * rg + e] = -dlt[qi];
+        }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qb_ + fr * RB + (((2 * ks + fh) ^ r_sw) << 4));
+        const bf16x8 ga = *reinterpret_cast<const bf16x8*>(gb_ + fr * RB + (((2 * ks + fh) ^ r_sw) << 4));
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
+      }
+      bf16x8 pf[2], dsf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        float pr = exp2f(st[r] * c);
+        if (key_dead || qi >= p.L || (causal && kj > qi + p.start_pos)) pr = 0.f;
+        pf[r >> 3][r & 7] = (bf16)pr;
+        dsf[r >> 3][r & 7] = (bf16)(pr * dp[r]);
+      }
+      // dV^T[d][key] += dO^T[d][q] . P[q][key];   dK^T[d][key] += Q^T[d][q] . dS[q][key]
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int row = 16 * s + t_row;
+          const int chunk = 4 * n + 2 * g16 + ((li & 3) >> 1);
+          const int o0 = row * RB + ((chunk ^ dual_sw(row)) << 4) + 8 * (li & 1);
+          const int o1 = (row + 8) * RB + ((chunk ^ dual_sw(row + 8)) << 4) + 8 * (li & 1);
+          union { struct { s16x4 a, b; } s_; bf16x8 v; } ug, uq;
+          ug.s_.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(gb_ + o0));
+          ug.s_.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(gb_ + o1));
+          uq.s_.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(qb_ + o0));
+          uq.s_.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(qb_ + o1));
+          dv[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ug.v, pf[s], dv[n], 0, 0, 0);
+          dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uq.v, dsf[s], dk[n], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+  }
+  if (kj < p.S) {
+    bf16* DK = p.dk + (int64_t)b * p.dk_sb + (int64_t)kvh * p.dk_sh + (int64_t)kj * p.dk_sl;
+    bf16* DV = p.dv + (int64_t)b * p.dv_sb + (int64_t)kvh * p.dv_sh + (int64_t)kj * p.dv_sl;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        bf16x4 a, w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (bf16)(dk[n][4 * rg + e] * p.scale); w[e] = (bf16)dv[n][4 * rg + e]; }
+        *reinterpret_cast<bf16x4*>(DK + 32 * n + 8 * rg + 4 * fh) = a;
+        *reinterpret_cast<bf16x4*>(DV + 32 * n + 8 * rg + 4 * fh) = w;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
+                               int64_t lddw, float* db, float beta, int64_t M, int64_t N, int64_t K,
+                               int dtype, void* stream) {
+  const char* who = "vy_linear_wgrad";
+  if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only (fp32 is the inference parity path)", who);
+  if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0) VY_FAIL(VY_ERR_ARG, "%s: bad arguments", who);
+  if (N % 8 || K % 8 || lddy % 8 || ldx % 8 || (uintptr_t)dy % 16 || (uintptr_t)x % 16)
+    VY_FAIL(VY_ERR_ARG, "%s: N, K and leading dimensions must be multiples of 8, operands 16-byte aligned", who);
+  if (beta != 0.f && beta != 1.f) VY_FAIL(VY_ERR_ARG, "%s: beta must be 0 or 1", who);
+  hipStream_t st = (hipStream_t)stream;
+  if (beta == 0.f) {
+    if (hipMemset2DAsync(dw, lddw * sizeof(float), 0, K * sizeof(float), N, st) != hipSuccess)
+      VY_FAIL(VY_ERR_LAUNCH, "%s: memset failed", who);
+    if (db && hipMemsetAsync(db, 0, N * sizeof(float), st) != hipSuccess)
+      VY_FAIL(VY_ERR_LAUNCH, "%s: memset failed", who);
+  }
+  const int tiles_n = (int)vy_cdiv(N, 128), tiles_k = (int)vy_cdiv(K, 128);
+  const int tiles = tiles_n * tiles_k;
+  int64_t splits = vy_cdiv(384, tiles);                      // ~1.5 workgroups per CU; bounds the atomic bytes
+  const int64_t max_splits = vy_cdiv(M, 256);                // >= 4 stages of 64 rows each
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int64_t m_chunk = vy_cdiv(vy_cdiv(M, splits), 64) * 64;
+  splits = vy_cdiv(M, m_chunk);
+  hipLaunchKernelGGL(wgrad_tn_bf16_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
+                     lddy, (const bf16*)x, ldx, dw, lddw, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk);
+  VY_CHECK_LAUNCH(who);
+  if (db) {
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)vy_cdiv(N, 512), (unsigned)vy_cdiv(M, 256)), dim3(64), 0,
+                       st, (const bf16*)dy, lddy, db, (int)M, (int)N);
+    VY_CHECK_LAUNCH("vy_linear_wgrad(colsum)");
+  }
+  return VY_OK;
+}
+
+extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl, const void* k,
+                           int64_t k_sb, int64_t k_sh, int64_t k_sl, const void* v, int64_t v_sb,
+                           int64_t v_sh, int64_t v_sl, const void* out, const void* dout, int64_t o_sb,
+                           int64_t o_sl, const float* lse, float* delta_ws, void* dq, int64_t dq_sb,
+                           int64_t dq_sh, int64_t dq_sl, void* dk, int64_t dk_sb, int64_t dk_sh,
+                           int64_t dk_sl, void* dv, int64_t dv_sb, int64_t dv_sh, int64_t dv_sl,
+                           int mask_kind, int64_t start_pos, const uint8_t* keypad, int64_t kp_sb, int64_t B,
+                           int h, int hk, int64_t L, int64_t S, int dh, float scale, int dtype, void* stream) {
+  const char* who = "vy_attn_bwd";
+  if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only", who);
+  if (dh != 64) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: head_dim %d (only 64 has a backward kernel yet)", who, dh);
+  if (mask_kind & VY_MASK_ADDITIVE) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: generic additive masks have no backward; use causal/key-padding descriptors", who);
+  if (!q || !k || !v || !out || !dout || !lse || !delta_ws || !dq || !dk || !dv) VY_FAIL(VY_ERR_ARG, "%s: null tensor", who);
+  if (B <= 0 || h <= 0 || hk <= 0 || h % hk || L <= 0 || S <= 0) VY_FAIL(VY_ERR_ARG, "%s: bad sizes", who);
+  if ((mask_kind & VY_MASK_KEYPAD) && !keypad) VY_FAIL(VY_ERR_ARG, "%s: keypad mask requested but NULL", who);
+  const int64_t s8[] = {q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sl,
+                        dq_sb, dq_sh, dq_sl, dk_sb, dk_sh, dk_sl, dv_sb, dv_sh, dv_sl};
+  for (int64_t x : s8)
+    if (x % 8) VY_FAIL(VY_ERR_ARG, "%s: strides must be multiples of 8 elements", who);
+  BwdParams p;
+  p.q = (const bf16*)q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = q_sl;
+  p.k = (const bf16*)k; p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;
+  p.v = (const bf16*)v; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
+  p.o = (const bf16*)out; p.dout = (const bf16*)dout; p.o_sb = o_sb; p.o_sl = o_sl;
+  p.lse = lse; p.delta = delta_ws;
+  p.dq = (bf16*)dq; p.dq_sb = dq_sb; p.dq_sh = dq_sh; p.dq_sl = dq_sl;
+  p.dk = (bf16*)dk; p.dk_sb = dk_sb; p.dk_sh = dk_sh; p.dk_sl = dk_sl;
+  p.dv = (bf16*)dv; p.dv_sb = dv_sb; p.dv_sh = dv_sh; p.dv_sl = dv_sl;
+  p.mask_kind = mask_kind; p.start_pos = (int)start_pos; p.keypad = keypad; p.kp_sb = kp_sb;
+  p.B = (int)B; p.h = h; p.hk = hk; p.L = (int)L; p.S = (int)S; p.scale = scale;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)vy_cdiv(B * L, 4)), dim3(256), 0, st, p);
+  VY_CHECK_LAUNCH("vy_attn_bwd(delta)");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((L + 127) / 128), (unsigned)h, (unsigned)B), dim3(256), 0, st, p);
+  VY_CHECK_LAUNCH("vy_attn_bwd(dq)");
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)((S + 127) / 128), (unsigned)hk, (unsigned)B), dim3(256), 0, st, p);
+  VY_CHECK_LAUNCH("vy_attn_bwd(dkdv)");
+  return VY_OK;
 }

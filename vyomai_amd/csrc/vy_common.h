@@ -34,8 +34,9 @@ void vy_set_error(const char* fmt, ...);
 
 static inline int64_t vy_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// 16 zero bytes: source for K-tail chunks of LDS-DMA loads.
-extern __device__ uint32_t vy_zero16[4];
+// 16 zero bytes: source for out-of-range chunks of LDS-DMA loads (one copy per translation unit:
+// the library is built without relocatable device code).
+static __device__ __attribute__((aligned(16))) uint32_t vy_zero16[4] = {0, 0, 0, 0};
 
 // device helpers ------------------------------------------------------------------------
 __device__ __forceinline__ float vy_gelu_erf(float x) {

@@ -20,8 +20,6 @@
 // Reference semantics: nn.Linear call sites listed in include/vyom_hip.h.
 #include "vy_common.h"
 
-__device__ uint32_t vy_zero16[4] = {0, 0, 0, 0};
-
 namespace {
 
 // ------------------------------------------------------------------------------------------

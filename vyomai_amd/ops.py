@@ -174,3 +174,97 @@ def rope_tables(head_dim: int, max_pos: int, device) -> Tuple[Tensor, Tensor]:
     t = torch.arange(max_pos).type_as(inv_freq)
     ang = torch.einsum("i,j->ij", t, inv_freq)
     return ang.cos().contiguous().to(device), ang.sin().contiguous().to(device)
+
+
+# ------------------------------------------------------------------------------------------
+# backward / training entry points
+# ------------------------------------------------------------------------------------------
+
+
+def linear_dgrad(dy: Tensor, wt: Tensor, pre: Optional[Tensor] = None, act: int = _lib.ACT_NONE,
+                 add_to: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """dX = (dY @ W) * act'(pre) + add_to, with W^T given ([K, N] row-major).  (vy_linear_dgrad)"""
+    _need_gpu(dy, wt, pre, add_to)
+    d2 = _rows(dy)
+    M, N = d2.shape
+    K = wt.shape[0]
+    assert wt.shape[1] == N and wt.stride(1) == 1
+    if out is None:
+        out = torch.empty((*dy.shape[:-1], K), dtype=dy.dtype, device=dy.device)
+    o2 = _rows(out)
+    p2 = _rows(pre) if pre is not None else None
+    a2 = _rows(add_to) if add_to is not None else None
+    call("vy_linear_dgrad", d2.data_ptr(), d2.stride(0), wt.data_ptr(), wt.stride(0), _ptr(p2),
+         p2.stride(0) if p2 is not None else 0, act, _ptr(a2), a2.stride(0) if a2 is not None else 0,
+         o2.data_ptr(), o2.stride(0), M, N, K, dtype_code(dy.dtype), _stream())
+    return out
+
+
+def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], accumulate: bool) -> None:
+    """dw (fp32 [N,K]) (+)= dy^T @ x ; db (fp32 [N]) (+)= colsum(dy).  (vy_linear_wgrad)"""
+    _need_gpu(dy, x, dw, db)
+    d2, x2 = _rows(dy), _rows(x)
+    M, N = d2.shape
+    K = x2.shape[1]
+    assert dw.dtype == torch.float32 and dw.shape == (N, K) and dw.stride(1) == 1
+    call("vy_linear_wgrad", d2.data_ptr(), d2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(),
+         dw.stride(0), _ptr(db), 1.0 if accumulate else 0.0, M, N, K, dtype_code(dy.dtype), _stream())
+
+
+def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor,
+                  dbeta: Tensor, accumulate: bool) -> Tensor:
+    _need_gpu(dy, x, gamma, mean, rstd, dgamma, dbeta)
+    d2, x2 = _rows(dy), _rows(x)
+    M, N = x2.shape
+    dx = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    W = _lib.load().vy_layernorm_bwd_ws_rows(M)
+    ws = torch.empty((2 * W * N,), dtype=torch.float32, device=x.device)
+    call("vy_layernorm_bwd", d2.data_ptr(), d2.stride(0), x2.data_ptr(), x2.stride(0), gamma.data_ptr(),
+         mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dx.stride(0), dgamma.data_ptr(), dbeta.data_ptr(),
+         1.0 if accumulate else 0.0, ws.data_ptr(), M, N, dtype_code(x.dtype), _stream())
+    return dx.view(x.shape)
+
+
+def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, causal: bool, start_pos: int = 0,
+                  keypad: Optional[Tensor] = None, scale: Optional[float] = None) -> None:
+    """Flash attention backward; dq/dk/dv are (B, heads, L|S, dh) views written in place."""
+    _need_gpu(q, k, v, out, dout, lse, dq, dk, dv, keypad)
+    B, h, L, dh = q.shape
+    hk, S = k.shape[1], k.shape[2]
+    kind = (_lib.MASK_CAUSAL if causal else 0) | (_lib.MASK_KEYPAD if keypad is not None else 0)
+    if scale is None:
+        scale = 1.0 / math.sqrt(dh)
+    assert out.stride() == dout.stride() and out.stride(2) == 1
+    delta = torch.empty((B, h, L), dtype=torch.float32, device=q.device)
+    call("vy_attn_bwd", q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
+         k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
+         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
+         out.data_ptr(), dout.data_ptr(), out.stride(0), out.stride(1), lse.data_ptr(), delta.data_ptr(),
+         dq.data_ptr(), dq.stride(0), dq.stride(1), dq.stride(2),
+         dk.data_ptr(), dk.stride(0), dk.stride(1), dk.stride(2),
+         dv.data_ptr(), dv.stride(0), dv.stride(1), dv.stride(2),
+         kind, start_pos, _ptr(keypad), keypad.stride(0) if keypad is not None else 0,
+         B, h, hk, L, S, dh, float(scale), dtype_code(q.dtype), _stream())
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tensor], lr: float,
+               beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
+               grad_scale: float = 1.0) -> None:
+    _need_gpu(p, g, m, v, p_bf16)
+    call("vy_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), p.numel(),
+         lr, beta1, beta2, eps, weight_decay, step, grad_scale, _stream())
+
+
+def transpose(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    _need_gpu(x)
+    R, C = x.shape
+    if out is None:
+        out = torch.empty((C, R), dtype=x.dtype, device=x.device)
+    call("vy_transpose", x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, C, dtype_code(x.dtype), _stream())
+    return out
+
+
+def cast(src: Tensor, dst: Tensor) -> Tensor:
+    _need_gpu(src, dst)
+    call("vy_cast", src.data_ptr(), dst.data_ptr(), src.numel(), dtype_code(src.dtype), dtype_code(dst.dtype), _stream())
+    return dst
