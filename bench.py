@@ -1,0 +1,293 @@
+"""Benchmark of the VyomAI transformer hot path on MI355X (driver contract: see the task brief).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* = one CLM training step (forward + backward + gradient all-reduce + fused AdamW) of the
+GPT-style decoder of BASELINE.json configs[1]: 12 layers, d=768, 12 heads, RoPE, vocab 50265,
+per-GPU batch 32 x seq 512, bf16 kernels with fp32 master weights, synthetic tokens, recipe
+weights.  `value` = whole-job training tokens/s (weak scaling: per-GPU work fixed).  After the
+timed training region the same run measures KV-cache greedy decode (512-token prompts, 128 new
+tokens, static cache) and reports it as `decode_tokens_per_sec`.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = the bf16 MFMA GEMM (forward projections/FFN of one step); achieved
+                = algorithmic FLOPs / HIP-event time of those launches, measured live on the launch
+                stream; peak = 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).  `block_forward`
+                reports the attention+FFN block forward (the north-star 40 % target) the same way.
+  cpu_baseline  the CPU oracle (plain-torch restatement of the reference, pinned to reference-made
+                golden vectors) timed on the host cores on a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--decode-tokens", type=int, default=128)
+    ap.add_argument("--attn", default="none", choices=["none", "gqa"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    return ap.parse_args()
+
+
+def make_cfg(a):
+    from vyomai_amd import EncoderConfig
+    cfg = EncoderConfig(num_hidden_layers=a.layers, max_position_embeddings=1024, hidden_dropout_prob=0.0)
+    if a.attn == "gqa":
+        cfg.num_key_value_heads = 4
+    return cfg
+
+
+def block_flops_per_token(d, S):
+    """forward FLOPs of one attention+FFN block per token, causal attention counted as 2*S*d
+    (BASELINE.md section 4)."""
+    return 24 * d * d + 2 * S * d
+
+
+def event_time_us(fn, iters, stream):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    s.record(stream)
+    for _ in range(iters):
+        fn()
+    e.record(stream)
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters
+
+
+def roofline_probe(cfg, B, L, dev):
+    """Time the dominant kernel and the block forward on the stream they are launched on."""
+    from vyomai_amd import ops
+    d, h = cfg.hidden_size, cfg.num_attention_heads
+    dh = d // h
+    M = B * L
+    bf = torch.bfloat16
+    st = torch.cuda.current_stream()
+    g = torch.Generator().manual_seed(7)
+    r = lambda *s: torch.randn(*s, generator=g).to(bf).to(dev)
+    x = r(M, d)
+    x3 = x.view(B, L, d)
+    wqkv, bqkv = r(3 * d, d) / math.sqrt(d), r(3 * d)
+    wo, bo = r(d, d) / math.sqrt(d), r(d)
+    w1, b1 = r(4 * d, d) / math.sqrt(d), r(4 * d)
+    w2, b2 = r(d, 4 * d) / math.sqrt(4 * d), r(d)
+    gam, bet = r(d), r(d)
+    cos, sin = ops.rope_tables(dh, 1024, dev)
+    q = torch.empty(B, h, L, dh, dtype=bf, device=dev)
+    k, v = torch.empty_like(q), torch.empty_like(q)
+    o = torch.empty(B, L, d, dtype=bf, device=dev)
+    s1 = torch.empty(M, d, dtype=bf, device=dev)
+    hm = torch.empty(M, 4 * d, dtype=bf, device=dev)
+
+    def gemms():
+        ops.qkv_rope(x3, wqkv, bqkv, h, h, dh, cos, sin, 0, q, k, v)
+        ops.linear(x, wo, bo, residual=x, out=s1)
+        ops.linear(x, w1, b1, act=1, out=hm)
+        ops.linear(hm, w2, b2, residual=x, out=s1)
+
+    def block():
+        ops.qkv_rope(x3, wqkv, bqkv, h, h, dh, cos, sin, 0, q, k, v)
+        ops.attention(q, k, v, causal=True, out=o)
+        ops.linear(o.view(M, d), wo, bo, residual=x, out=s1)
+        ops.layernorm(s1, gam, bet, 1e-5)
+        ops.linear(s1, w1, b1, act=1, out=hm)
+        ops.linear(hm, w2, b2, residual=x, out=s1)
+        ops.layernorm(s1, gam, bet, 1e-5)
+
+    t_gemm = event_time_us(gemms, 10, st)
+    t_blk = event_time_us(block, 10, st)
+    f_gemm = 24.0 * d * d * M
+    f_blk = block_flops_per_token(d, L) * M
+    return {
+        "bound": "mfma", "kernel": "gemm_nt_bf16_kernel (4 launches of one layer: qkv+rope, out+res, ffn1+gelu, ffn2+res)",
+        "achieved": round(f_gemm / t_gemm * 1e-6, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(f_gemm / t_gemm * 1e-6 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        "avg_launch_us": round(t_gemm / 4, 1), "flops_per_launch": f_gemm / 4,
+        "block_forward": {"us": round(t_blk, 1), "achieved": round(f_blk / t_blk * 1e-6, 1),
+                          "frac": round(f_blk / t_blk * 1e-6 / PEAK_BF16_TFLOPS, 4),
+                          "flops": f_blk, "convention": "24 d^2 + 2 S d per token (causal)"},
+    }
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask and cgroup quota, not the node size."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cfg, seq):
+    """The oracle (CPU restatement of the reference) timed on the host: forward+backward of the
+    12-layer decoder on a bounded sample (B=2 x seq) -> training tokens/s on the CPU."""
+    from oracle import vyom_oracle as O
+    from tests.golden import cases
+    from vyomai_amd import recipe
+    nthreads = host_cores()
+    torch.set_num_threads(nthreads)
+    shapes = cases.text_model_shapes(cfg, "rope", None, head=True)
+    sd = {}
+    for n, s in shapes.items():
+        if n.endswith("decoder.bias"):
+            continue
+        sd[n] = torch.from_numpy(recipe.param_value(n, s)).requires_grad_(True)
+    sd["lm_head.decoder.bias"] = sd["lm_head.bias"]
+    c = O.Cfg.of(cfg)
+    B = 1
+    ids = torch.from_numpy(recipe.token_ids("bench.cpu", (B, seq), 3, cfg.vocab_size))
+    t0 = time.time()
+    n = 0
+    while True:
+        out = O.decoder_forward(sd, c, ids, None, "rope", None, fused_sdpa=True)
+        loss = O.clm_loss(out.logits, ids)
+        loss.backward()
+        n += 1
+        if time.time() - t0 > 10 or n >= 4:
+            break
+    dt = time.time() - t0
+    return {"value": round(n * B * seq / dt, 1), "unit": "tokens/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} fwd+bwd passes of the 12L decoder oracle at B={B} x seq={seq}, fp32, no optimizer step"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vyomai_amd as V
+    from vyomai_amd import recipe
+    from vyomai_amd.training import FlatTrainer
+
+    cfg = make_cfg(a)
+    at = None if a.attn == "none" else "gqa"
+    model = V.DecoderModel(cfg, "rope", at)
+    recipe.load_recipe_(model)
+    model = model.to(dev).train()
+    trainer = FlatTrainer(model, lr=5e-5, weight_decay=0.01)
+    B, L = a.batch, a.seq
+    torch.manual_seed(1234 + rank)
+    ids = torch.randint(3, cfg.vocab_size, (B, L), device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return trainer.train_step(lambda: model.clm_loss(ids, ids))
+
+    for _ in range(a.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    tokens = world * B * L * a.steps
+    final_loss = float(loss.item())
+
+    # ---- decode: replicas only (independent sequences per GPU, no collective) -------------------
+    dec = None
+    if not a.no_decode:
+        model.eval()
+        with torch.no_grad():
+            am = torch.ones(B, L, dtype=torch.long, device=dev)
+            mb = model  # fp32 masters + bf16 shadows: run the decode in bf16 via compute_dtype
+            torch.cuda.synchronize()
+            # prefill + n tokens; time the token loop only via two runs (n and 1 new tokens)
+            def gen(n):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                mb.generate(ids, am, max_len=n, use_cache=True, use_static_cache=True)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t
+            gen(2)
+            t1 = gen(1)
+            tn = gen(a.decode_tokens)
+            per_tok = (tn - t1) / max(1, a.decode_tokens - 1)
+            tm = torch.tensor([per_tok], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            per_tok = float(tm.item())
+            dec = {"tokens_per_sec": round(world * B / per_tok, 1), "ms_per_token_step": round(per_tok * 1e3, 3),
+                   "prefill_plus_first_token_ms": round(t1 * 1e3, 2), "batch": B, "prompt": L,
+                   "new_tokens": a.decode_tokens, "cache": "StaticCacheOne", "scaling": "replicas only"}
+        model.train()
+
+    roof = cpu = None
+    if rank == 0:
+        roof = roofline_probe(cfg, B, L, dev)
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, L)
+    if rank == 0:
+        d = cfg.hidden_size
+        fl_step = 3.0 * (block_flops_per_token(d, L) * cfg.num_hidden_layers + 2 * d * d + 2 * d * cfg.vocab_size) * B * L
+        line = {
+            "metric": "training tokens/sec (12L d=768 seq=512 GPT-style decoder, CLM)",
+            "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: GPT-style Decoder {cfg.num_hidden_layers}L d=768 h=12 RoPE vocab 50265, "
+                                   f"CLM training B={B}/GPU seq={L}, AdamW, bf16 kernels + fp32 masters; "
+                                   f"then KV-cache greedy decode {a.decode_tokens} tok",
+                       "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
+                       "attention": a.attn, "weights": "deterministic recipe (vyomai_amd.recipe)"},
+            "final_loss": round(final_loss, 4),
+            "train_model_tflops": round(fl_step * world * a.steps / dt * 1e-12, 1),
+            "decode_tokens_per_sec": dec["tokens_per_sec"] if dec else None,
+            "decode": dec,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,22 @@ int vy_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, in
                   float beta1, float beta2, float eps, float weight_decay, int64_t step,
                   float grad_scale, void* stream);
 
+/* dx = dy * act'(pre), elementwise over [M,N] row-major views (GELU backward outside a GEMM). */
+int vy_act_bwd(const void* dy, int64_t lddy, const void* pre, int64_t ldpre, void* dx, int64_t lddx,
+               int64_t M, int64_t N, int act, int dtype, void* stream);
+
+/* Softmax cross-entropy over the vocabulary, ignore_index aware (the CLM loss of
+ * Examples/vyom-ai-decoder_clm.ipynb cell 29 after the label shift).
+ * fwd: lse[m] = logsumexp(logits[m,:V]); loss_sum += sum_m (lse[m] - logits[m,label]) and
+ *      count += #(label != ignore) -- both fp32 scalars on the device, accumulated atomically
+ *      (zero them first).
+ * bwd: logits[m,:] <- (softmax(logits[m,:]) - onehot(label)) * (*gscale) / (*count), in place
+ *      (rows with label == ignore become 0); gscale/count are device pointers: no host sync. */
+int vy_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, float* lse,
+                float* loss_sum, float* count, int64_t M, int64_t V, int dtype, void* stream);
+int vy_xent_bwd(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, const float* lse,
+                const float* gscale, const float* count, int64_t M, int64_t V, int dtype, void* stream);
+
 /* out[c, r] = in[r, c] for a [R,C] matrix (bf16 or f32): keeps W^T copies for dgrad. */
 int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t R, int64_t C,
                  int dtype, void* stream);

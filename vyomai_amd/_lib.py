@@ -39,6 +39,9 @@ PROTOTYPES = {
                     _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,
                     _i, _i64, _p, _i64, _i64, _i, _i, _i64, _i64, _i, _f, _i, _p],
     "vy_adamw_step": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p],
+    "vy_act_bwd": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
+    "vy_xent_fwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
+    "vy_xent_bwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
     "vy_transpose": [_p, _i64, _p, _i64, _i64, _i64, _i, _p],
     "vy_cast": [_p, _p, _i64, _i, _i, _p],
 }

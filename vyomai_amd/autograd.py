@@ -93,7 +93,7 @@ def self_attention_block(mod, x, attention_mask, freqs, cache, cache_index, star
         if cache is not None:
             raise VyomHipError("KV caching is an inference feature; call under torch.no_grad()")
         from .autograd_train import SelfAttentionFn
-        o = SelfAttentionFn.apply(x, w, b, mod, attention_mask, freqs, start_pos)
+        o = SelfAttentionFn.apply(x, mod, attention_mask, freqs, start_pos, *mod._params())
         return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
                                          aso.layernorm.bias, aso.layernorm.eps)
     cos, sin, pos0 = resolve_freqs(freqs, dev)

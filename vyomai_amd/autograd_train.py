@@ -1,0 +1,362 @@
+"""torch.autograd.Function wrappers whose forward AND backward are HIP kernel launches.
+
+PyTorch supplies the tape only.  Parameters stay fp32 (master weights); activations and the
+weights the kernels read are bf16 copies (``_shadow``), refreshed by the fused AdamW kernel when
+the FlatTrainer owns the parameters.
+
+Gradient delivery has two modes per parameter:
+  * direct   -- ``param.grad`` is a preallocated fp32 view into the trainer's flat gradient arena
+               (``param._vy_direct``): wgrad kernels accumulate straight into it (no temporaries,
+               contiguous buckets for the RCCL reducer) and autograd receives ``None``;
+  * returned -- otherwise a fresh fp32 gradient is computed and handed back to autograd.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._lib import ACT_GELU_ERF, ACT_NONE, VyomHipError
+from .layers.attention import _shadow
+from .layers.mask import AttnMask
+from .layers.positional_embeddings import resolve_freqs
+
+BF16 = torch.bfloat16
+
+
+# bumped by FlatTrainer.step(): its AdamW kernel rewrites weights without touching tensor versions
+WEIGHT_EPOCH = [0]
+
+
+def _wt(param: torch.Tensor, dtype) -> torch.Tensor:
+    """W^T ([K, N], row stride padded to 8) of a 2-D parameter in `dtype`, cached per version."""
+    cache = getattr(param, "_vy_wt", None)
+    src = _shadow(param, dtype)
+    key = (param._version, WEIGHT_EPOCH[0])
+    if cache is None or cache[0] != key or cache[1].dtype != dtype:
+        N, K = src.shape
+        ld = (N + 7) // 8 * 8
+        buf = torch.zeros((K, ld), dtype=dtype, device=src.device)
+        ops.transpose(src, buf[:, :N])
+        cache = (key, buf[:, :N])
+        param._vy_wt = cache
+    return cache[1]
+
+
+def _direct(p: Optional[torch.Tensor]) -> bool:
+    return p is not None and getattr(p, "_vy_direct", False) and p.grad is not None
+
+
+def _notify(*params) -> None:
+    for p in params:
+        if p is not None:
+            cb = getattr(p, "_vy_ready", None)
+            if cb is not None:
+                cb(p)
+
+
+def _wgrad(dy, x, w: torch.Tensor, b: Optional[torch.Tensor]):
+    """-> (dw, db) to return to autograd (None when accumulated in place)."""
+    if _direct(w) and (b is None or _direct(b)):
+        ops.linear_wgrad(dy, x, w.grad, None if b is None else b.grad, accumulate=True)
+        _notify(w, b)
+        return None, None
+    dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
+    db = torch.empty(b.shape, dtype=torch.float32, device=w.device) if b is not None else None
+    ops.linear_wgrad(dy, x, dw, db, accumulate=False)
+    return dw.to(w.dtype), (db.to(b.dtype) if b is not None else None)
+
+
+def _ln_bwd(dy, x, ln_w, ln_b, mean, rstd):
+    dt = x.dtype
+    if _direct(ln_w) and _direct(ln_b):
+        dx = ops.layernorm_bwd(dy, x, _shadow(ln_w, dt), mean, rstd, ln_w.grad, ln_b.grad, accumulate=True)
+        _notify(ln_w, ln_b)
+        return dx, None, None
+    dg = torch.empty(ln_w.shape, dtype=torch.float32, device=x.device)
+    db = torch.empty(ln_b.shape, dtype=torch.float32, device=x.device)
+    dx = ops.layernorm_bwd(dy, x, _shadow(ln_w, dt), mean, rstd, dg, db, accumulate=False)
+    return dx, dg.to(ln_w.dtype), db.to(ln_b.dtype)
+
+
+def _require_bf16(x: torch.Tensor) -> None:
+    if x.dtype != BF16:
+        raise VyomHipError("training kernels are bf16 (fp32 master weights): feed bf16 activations, e.g. via "
+                           "vyomai_amd.training.FlatTrainer or model.compute_dtype = torch.bfloat16")
+
+
+class LinearResidualLayerNormFn(torch.autograd.Function):
+    """y = LN(x W^T + b + residual).  AttentionSelfOutput (reference layers/attention.py:69-72)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w, b, ln_w, ln_b, eps):
+        _require_bf16(x)
+        dt = x.dtype
+        s = ops.linear(x, _shadow(w, dt), _shadow(b, dt), residual=residual)
+        y, mean, rstd = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
+        ctx.save_for_backward(x, s, mean, rstd)
+        ctx.params = (w, b, ln_w, ln_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s, mean, rstd = ctx.saved_tensors
+        w, b, ln_w, ln_b = ctx.params
+        dy = dy.contiguous()
+        ds, dg, dbt = _ln_bwd(dy, s, ln_w, ln_b, mean, rstd)
+        dx = ops.linear_dgrad(ds, _wt(w, x.dtype))
+        dw, db = _wgrad(ds, x, w, b)
+        return dx, ds, dw, db, dg, dbt, None
+
+
+class FfnBlockFn(torch.autograd.Function):
+    """y = LN(act(x W1^T + b1) W2^T + b2 + residual).  FeedForward (reference layers/ffn.py:32-40)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act):
+        _require_bf16(x)
+        dt = x.dtype
+        pre = torch.empty((*x.shape[:-1], w1.shape[0]), dtype=dt, device=x.device)
+        hmid = torch.empty_like(pre)
+        ops.linear(x, _shadow(w1, dt), _shadow(b1, dt), act=act, pre_out=pre, out=hmid)
+        s = ops.linear(hmid, _shadow(w2, dt), _shadow(b2, dt), residual=residual)
+        y, mean, rstd = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
+        ctx.save_for_backward(x, pre, hmid, s, mean, rstd)
+        ctx.params = (w1, b1, w2, b2, ln_w, ln_b)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre, hmid, s, mean, rstd = ctx.saved_tensors
+        w1, b1, w2, b2, ln_w, ln_b = ctx.params
+        dt = x.dtype
+        dy = dy.contiguous()
+        ds, dg, dbt = _ln_bwd(dy, s, ln_w, ln_b, mean, rstd)
+        dpre = ops.linear_dgrad(ds, _wt(w2, dt), pre=pre, act=ctx.act)  # (ds W2) * act'(pre)
+        dw2, db2 = _wgrad(ds, hmid, w2, b2)
+        dx = ops.linear_dgrad(dpre, _wt(w1, dt))
+        dw1, db1 = _wgrad(dpre, x, w1, b1)
+        return dx, ds, dw1, db1, dw2, db2, dg, dbt, None, None
+
+
+class SelfAttentionFn(torch.autograd.Function):
+    """o = merge_heads(softmax(rope(q) rope(k)^T / sqrt(dh) + mask) v) with q,k,v = x W^T + b.
+    Inputs after `mod` are the projection parameters in module order (q,k,v weights then biases,
+    or the fused qkv weight and bias)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, attention_mask, freqs, start_pos, *params):
+        _require_bf16(x)
+        B, L, _ = x.shape
+        h, hk, dh = mod.num_attention_heads, mod.num_key_value_heads, mod.head_dim
+        dt, dev = x.dtype, x.device
+        w, b = mod._packed()
+        if attention_mask is not None and not isinstance(attention_mask, AttnMask):
+            raise VyomHipError("training needs a mask descriptor (AttnMask): dense additive masks have no "
+                               "backward kernel")
+        cos, sin, pos0 = resolve_freqs(freqs, dev)
+        q = torch.empty((B, h, L, dh), dtype=dt, device=dev)
+        k = torch.empty((B, hk, L, dh), dtype=dt, device=dev)
+        v = torch.empty_like(k)
+        ops.qkv_rope(x, _shadow(w, dt), _shadow(b, dt), h, hk, dh, cos, sin, pos0, q, k, v)
+        lse = torch.empty((B, h, L), dtype=torch.float32, device=dev)
+        causal, kp, sp = False, None, 0
+        if attention_mask is not None:
+            causal, kp, sp = attention_mask.causal, attention_mask.keypad, attention_mask.start_pos
+            if kp is not None:
+                kp = kp[:, :L].contiguous() if kp.shape[1] != L else kp
+        o = ops.attention(q, k, v, causal=causal, start_pos=sp, keypad=kp, lse=lse)
+        ctx.save_for_backward(x, q, k, v, o, lse)
+        ctx.meta = (mod, causal, kp, sp, cos, sin, pos0, params)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        x, q, k, v, o, lse = ctx.saved_tensors
+        mod, causal, kp, sp, cos, sin, pos0, params = ctx.meta
+        B, L, _ = x.shape
+        h, hk, dh = mod.num_attention_heads, mod.num_key_value_heads, mod.head_dim
+        dt = x.dtype
+        do = do.contiguous()
+        W = (h + 2 * hk) * dh
+        packed = torch.empty((B, L, W), dtype=dt, device=x.device)  # [dq | dk | dv], 'b l (h d)'
+        dq = packed[:, :, : h * dh].view(B, L, h, dh).permute(0, 2, 1, 3)
+        dk = packed[:, :, h * dh:(h + hk) * dh].view(B, L, hk, dh).permute(0, 2, 1, 3)
+        dv = packed[:, :, (h + hk) * dh:].view(B, L, hk, dh).permute(0, 2, 1, 3)
+        ops.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, causal=causal, start_pos=sp, keypad=kp)
+        if cos is not None:  # RoPE is orthogonal: its backward is the inverse rotation
+            ops.rope_(dq, cos, sin, pos0, inverse=True)
+            ops.rope_(dk, cos, sin, pos0, inverse=True)
+        w, b = mod._packed()
+        dx = ops.linear_dgrad(packed, _wt_packed(mod, w, dt))
+        grads = _packed_wgrad(mod, packed, x, w, b, params)
+        return (dx, None, None, None, None, *grads)
+
+
+def _wt_packed(mod, w, dtype):
+    """W^T of the packed projection: keyed on the versions of the member parameters."""
+    members = mod._params()
+    key = tuple(p._version for p in members) + (WEIGHT_EPOCH[0],)
+    cache = getattr(mod, "_vy_wt_packed", None)
+    if cache is None or cache[0] != key or cache[1].dtype != dtype:
+        src = _shadow_packed(mod, w, dtype)
+        N, K = src.shape
+        buf = torch.empty((K, N), dtype=dtype, device=src.device)
+        ops.transpose(src, buf)
+        cache = (key, buf)
+        mod._vy_wt_packed = cache
+    return cache[1]
+
+
+def _shadow_packed(mod, w, dtype):
+    return _shadow(w, dtype)
+
+
+def _packed_wgrad(mod, dy, x, w, b, params):
+    members = mod._params()
+    nw = 1 if mod._fused_qkv else 3
+    ws, bs = members[:nw], members[nw:]
+    if all(_direct(p) for p in members):
+        # the trainer lays the member gradients out adjacently, mirroring the packed weights
+        g0 = ws[0].grad
+        N = sum(p.shape[0] for p in ws)
+        dw = torch.as_strided(g0, (N, g0.shape[1]), (g0.stride(0), 1))
+        ok = all(p.grad.data_ptr() == g0.data_ptr() + off * g0.shape[1] * 4
+                 for p, off in zip(ws, _offsets(ws)))
+        db = None
+        if bs:
+            db0 = bs[0].grad
+            db = torch.as_strided(db0, (N,), (1,))
+            ok = ok and all(p.grad.data_ptr() == db0.data_ptr() + off * 4 for p, off in zip(bs, _offsets(bs)))
+        if ok:
+            ops.linear_wgrad(dy, x, dw, db, accumulate=True)
+            _notify(*members)
+            return [None] * len(params)
+    N, K = w.shape
+    dw = torch.empty((N, K), dtype=torch.float32, device=w.device)
+    db = torch.empty((N,), dtype=torch.float32, device=w.device) if b is not None else None
+    ops.linear_wgrad(dy, x, dw, db, accumulate=False)
+    out, off = [], 0
+    for p in ws:
+        out.append(dw[off:off + p.shape[0]].to(p.dtype))
+        off += p.shape[0]
+    off = 0
+    for p in bs:
+        out.append(db[off:off + p.shape[0]].to(p.dtype))
+        off += p.shape[0]
+    return out
+
+
+def _offsets(ps):
+    offs, o = [], 0
+    for p in ps:
+        offs.append(o)
+        o += p.shape[0]
+    return offs
+
+
+class LMHeadFn(torch.autograd.Function):
+    """logits = LN(gelu(h Wd^T + bd)) Wv^T + bias (reference models/decoder.py:267-275).  The logits
+    row stride is padded to 8 and the pad columns are zero, so the backward GEMMs can contract
+    over the padded width."""
+
+    @staticmethod
+    def forward(ctx, hidden, wd, bd, ln_w, ln_b, wv, bias, eps):
+        _require_bf16(hidden)
+        dt = hidden.dtype
+        pre = torch.empty_like(hidden)
+        g = torch.empty_like(hidden)
+        ops.linear(hidden, _shadow(wd, dt), _shadow(bd, dt), act=ACT_GELU_ERF, pre_out=pre, out=g)
+        n, mean, rstd = ops.layernorm(g, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
+        V = wv.shape[0]
+        ld = (V + 7) // 8 * 8
+        buf = torch.zeros((*hidden.shape[:-1], ld), dtype=dt, device=hidden.device)
+        logits = buf[..., :V]
+        ops.linear(n, _shadow(wv, dt), _shadow(bias, dt), out=logits)
+        ctx.save_for_backward(hidden, pre, g, n, mean, rstd)
+        ctx.params = (wd, bd, ln_w, ln_b, wv, bias)
+        ctx.ld = ld
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        hidden, pre, g, n, mean, rstd = ctx.saved_tensors
+        wd, bd, ln_w, ln_b, wv, bias = ctx.params
+        dt = hidden.dtype
+        V, ld = wv.shape[0], ctx.ld
+        if dlogits.stride(-1) != 1 or dlogits.stride(-2) != ld:
+            buf = torch.zeros((*dlogits.shape[:-1], ld), dtype=dt, device=dlogits.device)
+            buf[..., :V] = dlogits
+            dlogits = buf[..., :V]
+        dn = ops.linear_dgrad(dlogits, _wt(wv, dt))
+        dwv, dbias = _wgrad(dlogits, n, wv, bias)
+        dg, dgam, dbet = _ln_bwd(dn, g, ln_w, ln_b, mean, rstd)
+        dpre = _gelu_bwd(dg, pre)
+        dh = ops.linear_dgrad(dpre, _wt(wd, dt))
+        dwd, dbd = _wgrad(dpre, hidden, wd, bd)
+        return dh, dwd, dbd, dgam, dbet, dwv, dbias, None
+
+
+def _gelu_bwd(dy, pre):
+    return ops.act_bwd(dy, pre, ACT_GELU_ERF)
+
+
+class LMHeadLossFn(torch.autograd.Function):
+    """Shifted causal-LM loss fused with the LM head: mean cross-entropy of logits[:, :-1] against
+    labels[:, 1:] with ignore_index (Examples/vyom-ai-decoder_clm.ipynb cell 29).  The logits
+    ([M, V] bf16, padded row stride) are produced by the vocabulary GEMM, reduced by vy_xent_fwd
+    and overwritten IN PLACE by their gradient in backward (vy_xent_bwd) -- they are never copied,
+    up-cast or re-materialised."""
+
+    @staticmethod
+    def forward(ctx, hidden, labels, ignore_index, wd, bd, ln_w, ln_b, wv, bias, eps):
+        _require_bf16(hidden)
+        dt, dev = hidden.dtype, hidden.device
+        B, L, _ = hidden.shape
+        pre = torch.empty_like(hidden)
+        g = torch.empty_like(hidden)
+        ops.linear(hidden, _shadow(wd, dt), _shadow(bd, dt), act=ACT_GELU_ERF, pre_out=pre, out=g)
+        n, mean, rstd = ops.layernorm(g, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
+        V = wv.shape[0]
+        ld = (V + 7) // 8 * 8
+        buf = torch.zeros((B * L, ld), dtype=dt, device=dev)
+        logits = buf[:, :V]
+        ops.linear(n.view(B * L, -1), _shadow(wv, dt), _shadow(bias, dt), out=logits)
+        shifted = torch.full((B, L), ignore_index, dtype=torch.long, device=dev)
+        shifted[:, :-1] = labels[:, 1:]
+        shifted = shifted.view(-1)
+        lse = torch.empty(B * L, dtype=torch.float32, device=dev)
+        acc = torch.zeros(2, dtype=torch.float32, device=dev)  # [loss_sum, count]
+        ops.xent_fwd(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2])
+        ctx.save_for_backward(hidden, pre, g, n, mean, rstd, buf, shifted, lse, acc)
+        ctx.params = (wd, bd, ln_w, ln_b, wv, bias)
+        ctx.ignore = ignore_index
+        return acc[0] / acc[1].clamp_min(1.0)
+
+    @staticmethod
+    def backward(ctx, gout):
+        hidden, pre, g, n, mean, rstd, buf, shifted, lse, acc = ctx.saved_tensors
+        wd, bd, ln_w, ln_b, wv, bias = ctx.params
+        dt = hidden.dtype
+        V = wv.shape[0]
+        logits = buf[:, :V]
+        gs = gout.detach().to(torch.float32).reshape(1).contiguous()
+        ops.xent_bwd_(logits, shifted, ctx.ignore, lse, gs, acc[1:2])   # logits <- dlogits
+        # contract over the padded vocabulary width (pad columns of both operands are zero)
+        dn = ops.linear_dgrad(buf, _wt_padded(wv, dt, buf.shape[1]))
+        dwv, dbias = _wgrad(logits, n.view(buf.shape[0], -1), wv, bias)
+        dg, dgam, dbet = _ln_bwd(dn.view(g.shape), g, ln_w, ln_b, mean, rstd)
+        dpre = _gelu_bwd(dg, pre)
+        dh = ops.linear_dgrad(dpre, _wt(wd, dt))
+        dwd, dbd = _wgrad(dpre, hidden, wd, bd)
+        return dh, None, None, dwd, dbd, dgam, dbet, dwv, dbias, None
+
+
+def _wt_padded(param, dtype, ld):
+    """[K, ld] zero-padded W^T (full padded width, for contractions over the padded vocabulary)."""
+    wt = _wt(param, dtype)
+    full = torch.as_strided(wt, (wt.shape[0], ld), (wt.stride(0), 1))
+    assert wt.stride(0) == ld
+    return full

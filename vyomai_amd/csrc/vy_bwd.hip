@@ -45,7 +45,8 @@ constexpr int WROW = 256;  // bytes per LDS row (128 bf16)
 
 __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
-    float* __restrict__ dW, int64_t lddw, int M, int N, int K, int tiles_k, int tiles_nk, int m_chunk) {
+    float* __restrict__ dW, int64_t lddw, float* __restrict__ db, int M, int N, int K, int tiles_k,
+    int tiles_nk, int m_chunk) {
   constexpr int STAGE = 2 * 64 * WROW;  // dY tile + X tile
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -93,6 +94,18 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // bias gradient db[n] = sum_m dY[m,n]: one extra MFMA against a ones operand in the k-tile-0
+  // workgroups (the dY fragments are already in registers); column 0 of the result is the sum
+  const bool do_db = db != nullptr && tile_k == 0 && wk == 0;
+  f32x16 accb[2];
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+
   const int li = lane & 15, g16 = (lane >> 4) & 1, fh = lane >> 5;
   const int tr_row = 4 * fh + (li >> 2);                  // + 16*s (second read +8)
   const int tr_sw = ((li >> 2) & 3) << 6;                 // (row & 3) << 6
@@ -121,11 +134,25 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      if (do_db) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, accb[i], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
   }
   const int fr = lane & 31;
+  if (do_db && fr == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (n < N) atomicAdd(db + n, accb[i][r]);
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -153,7 +180,8 @@ __global__ __launch_bounds__(64) void colsum_bf16_kernel(const bf16* __restrict_
     for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) atomicAdd(db + c0 + e, s[e]);
+  for (int e = 0; e < 8; ++e)
+    if (c0 + e < N) atomicAdd(db + c0 + e, s[e]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,8 +520,9 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   const char* who = "vy_linear_wgrad";
   if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only (fp32 is the inference parity path)", who);
   if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0) VY_FAIL(VY_ERR_ARG, "%s: bad arguments", who);
-  if (N % 8 || K % 8 || lddy % 8 || ldx % 8 || (uintptr_t)dy % 16 || (uintptr_t)x % 16)
-    VY_FAIL(VY_ERR_ARG, "%s: N, K and leading dimensions must be multiples of 8, operands 16-byte aligned", who);
+  // N may be odd (vocabulary) as long as every dY row is readable up to the next multiple of 8
+  if (K % 8 || lddy % 8 || ldx % 8 || lddy < vy_cdiv(N, 8) * 8 || (uintptr_t)dy % 16 || (uintptr_t)x % 16)
+    VY_FAIL(VY_ERR_ARG, "%s: K and leading dimensions must be multiples of 8 (lddy >= roundup8(N)), operands 16-byte aligned", who);
   if (beta != 0.f && beta != 1.f) VY_FAIL(VY_ERR_ARG, "%s: beta must be 0 or 1", who);
   hipStream_t st = (hipStream_t)stream;
   if (beta == 0.f) {
@@ -511,13 +540,8 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   int64_t m_chunk = vy_cdiv(vy_cdiv(M, splits), 64) * 64;
   splits = vy_cdiv(M, m_chunk);
   hipLaunchKernelGGL(wgrad_tn_bf16_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
-                     lddy, (const bf16*)x, ldx, dw, lddw, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk);
+                     lddy, (const bf16*)x, ldx, dw, lddw, db, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk);
   VY_CHECK_LAUNCH(who);
-  if (db) {
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)vy_cdiv(N, 512), (unsigned)vy_cdiv(M, 256)), dim3(64), 0,
-                       st, (const bf16*)dy, lddy, db, (int)M, (int)N);
-    VY_CHECK_LAUNCH("vy_linear_wgrad(colsum)");
-  }
   return VY_OK;
 }
 

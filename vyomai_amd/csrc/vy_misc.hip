@@ -175,14 +175,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 }
 
 // column sums of the [W, N] partial slabs: out = beta*out + sum_w ws[w][n]
-__global__ void colsum_partials_kernel(const float* __restrict__ ws, int W, int N, float* __restrict__ out0,
-                                       float* __restrict__ out1, float beta) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// block = 4 row groups x 64 columns; rows are strided over the groups, then reduced through LDS
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ ws, int W, int N,
+                                                              float* __restrict__ out0, float* __restrict__ out1,
+                                                              float beta) {
+  __shared__ float red[2][4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
   float a = 0.f, b = 0.f;
-  for (int w = 0; w < W; ++w) { a += ws[(int64_t)w * N + n]; b += ws[(int64_t)(W + w) * N + n]; }
-  if (out0) out0[n] = (beta != 0.f ? beta * out0[n] : 0.f) + a;
-  if (out1) out1[n] = (beta != 0.f ? beta * out1[n] : 0.f) + b;
+  if (n < N) {
+    for (int w = g; w < W; w += 4) {
+      a += ws[(int64_t)w * N + n];
+      b += ws[(int64_t)(W + w) * N + n];
+    }
+  }
+  red[0][g][c] = a; red[1][g][c] = b;
+  __syncthreads();
+  if (g == 0 && n < N) {
+    a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (out0) out0[n] = (beta != 0.f ? beta * out0[n] : 0.f) + a;
+    if (out1) out1[n] = (beta != 0.f ? beta * out1[n] : 0.f) + b;
+  }
 }
 
 // ---- RoPE (standalone, in place) ------------------------------------------------------------
@@ -288,6 +302,100 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---- activation backward (elementwise) ------------------------------------------------------
+template <typename T, int ACT>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ pre, int64_t ldpre,
+                               T* __restrict__ dx, int64_t lddx, int64_t M, int N) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int nch = N / VEC;
+  const int64_t total = M * nch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / nch;
+    const int c = (int)(i - m * nch) * VEC;
+    float a[VEC], b[VEC], o[VEC];
+    Chunk<T>::load(dy + m * lddy + c, a);
+    Chunk<T>::load(pre + m * ldpre + c, b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = a[e] * vy_act_grad<ACT>(b[e]);
+    Chunk<T>::store(dx + m * lddx + c, o);
+  }
+}
+
+// ---- softmax cross-entropy: one workgroup (4 waves) per row ------------------------------------
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  v = is_max ? vy_wave_max(v) : vy_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xent_fwd_kernel(const T* __restrict__ logits, int64_t ld,
+                                                       const int64_t* __restrict__ labels, int64_t ignore,
+                                                       float* __restrict__ lse, float* __restrict__ loss_sum,
+                                                       float* __restrict__ count, int V) {
+  constexpr int VEC = Chunk<T>::VEC;
+  __shared__ float red[4];
+  const int64_t m = blockIdx.x;
+  const int64_t label = labels[m];
+  if (label == ignore) { if (threadIdx.x == 0) lse[m] = 0.f; return; }
+  const T* row = logits + m * ld;
+  const int nch = (V + VEC - 1) / VEC;
+  float mx = -INFINITY, sm = 0.f;
+  for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+    float v[VEC];
+    Chunk<T>::load(row + (int64_t)c * VEC, v);  // the padded tail of the row is readable
+    float cm = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) if (c * VEC + e < V) cm = fmaxf(cm, v[e]);
+    const float nm = fmaxf(mx, cm);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) if (c * VEC + e < V) acc += __expf(v[e] - nm);
+    sm = sm * __expf(mx - nm) + acc;
+    mx = nm;
+  }
+  const float gmx = block_reduce(mx, red, true);
+  const float gsm = block_reduce(sm * __expf(mx - gmx), red, false);
+  if (threadIdx.x == 0) {
+    const float l = gmx + __logf(gsm);
+    lse[m] = l;
+    atomicAdd(loss_sum, l - VyT<T>::ld(row + label));
+    atomicAdd(count, 1.0f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void xent_bwd_kernel(T* __restrict__ logits, int64_t ld,
+                                                       const int64_t* __restrict__ labels, int64_t ignore,
+                                                       const float* __restrict__ lse, const float* __restrict__ gscale,
+                                                       const float* __restrict__ count, int V) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int64_t m = blockIdx.x;
+  const int64_t label = labels[m];
+  T* row = logits + m * ld;
+  const int nch = (V + VEC - 1) / VEC;
+  const bool dead = label == ignore;
+  const float sc = dead ? 0.f : (*gscale) / fmaxf(*count, 1.0f);
+  const float l = lse[m];
+  for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+    float v[VEC], o[VEC];
+    Chunk<T>::load(row + (int64_t)c * VEC, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int col = c * VEC + e;
+      float g = 0.f;
+      if (!dead && col < V) g = (__expf(v[e] - l) - (col == label ? 1.f : 0.f)) * sc;
+      o[e] = g;  // pad columns stay zero
+    }
+    Chunk<T>::store(row + (int64_t)c * VEC, o);
+  }
+}
+
 template <typename T>
 int ln_fwd_dispatch(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
                     float* mean, float* rstd, int64_t M, int64_t N, float eps, hipStream_t st) {
@@ -327,7 +435,7 @@ int ln_bwd_dispatch(const void* dy, int64_t lddy, const void* x, int64_t ldx, co
   else VY_FAIL(VY_ERR_UNSUPPORTED, "vy_layernorm_bwd: N=%ld too wide", (long)N);
 #undef LN_GO
   VY_CHECK_LAUNCH("vy_layernorm_bwd");
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)vy_cdiv(N, 256)), dim3(256), 0, st, ws, W, (int)N,
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)vy_cdiv(N, 64)), dim3(256), 0, st, ws, W, (int)N,
                      dgamma, dbeta, beta);
   VY_CHECK_LAUNCH("vy_layernorm_bwd(colsum)");
   return VY_OK;
@@ -345,7 +453,7 @@ extern "C" int vy_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, c
   VY_FAIL(VY_ERR_ARG, "vy_layernorm_fwd: bad dtype %d", dtype);
 }
 
-extern "C" int64_t vy_layernorm_bwd_ws_rows(int64_t M) { return M < 1024 ? (M < 1 ? 1 : M) : 1024; }
+extern "C" int64_t vy_layernorm_bwd_ws_rows(int64_t M) { return M < 512 ? (M < 1 ? 1 : M) : 512; }
 
 extern "C" int vy_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
                                 const float* mean, const float* rstd, void* dx, int64_t lddx, float* dgamma,
@@ -373,6 +481,51 @@ extern "C" int vy_rope_fwd(void* x, int64_t sb, int64_t sh, int64_t sl, const fl
     hipLaunchKernelGGL(rope_kernel<float>, grid, block, 0, st, (float*)x, sb, sh, sl, cos_tab, sin_tab, pos0, B, heads, L, dh, inverse);
   else VY_FAIL(VY_ERR_ARG, "vy_rope_fwd: bad dtype %d", dtype);
   VY_CHECK_LAUNCH("vy_rope_fwd");
+  return VY_OK;
+}
+
+extern "C" int vy_act_bwd(const void* dy, int64_t lddy, const void* pre, int64_t ldpre, void* dx, int64_t lddx,
+                          int64_t M, int64_t N, int act, int dtype, void* stream) {
+  if (!dy || !pre || !dx || M <= 0 || N <= 0) VY_FAIL(VY_ERR_ARG, "vy_act_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == VY_BF16 ? 8 : 4;
+  if (N % vec || lddy % vec || ldpre % vec || lddx % vec) VY_FAIL(VY_ERR_ARG, "vy_act_bwd: N/ld must be multiples of %d", vec);
+  const int64_t want = vy_cdiv(M * (N / vec), 256);
+  const dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
+#define AB_GO(T, A) hipLaunchKernelGGL((act_bwd_kernel<T, A>), grid, block, 0, st, (const T*)dy, lddy, (const T*)pre, ldpre, (T*)dx, lddx, M, (int)N)
+  if (dtype == VY_BF16 && act == VY_ACT_GELU_ERF) AB_GO(bf16, VY_ACT_GELU_ERF);
+  else if (dtype == VY_BF16 && act == VY_ACT_GELU_TANH) AB_GO(bf16, VY_ACT_GELU_TANH);
+  else if (dtype == VY_F32 && act == VY_ACT_GELU_ERF) AB_GO(float, VY_ACT_GELU_ERF);
+  else if (dtype == VY_F32 && act == VY_ACT_GELU_TANH) AB_GO(float, VY_ACT_GELU_TANH);
+  else VY_FAIL(VY_ERR_ARG, "vy_act_bwd: unsupported act %d / dtype %d", act, dtype);
+#undef AB_GO
+  VY_CHECK_LAUNCH("vy_act_bwd");
+  return VY_OK;
+}
+
+extern "C" int vy_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, float* lse,
+                           float* loss_sum, float* count, int64_t M, int64_t V, int dtype, void* stream) {
+  if (!logits || !labels || !lse || !loss_sum || !count || M <= 0 || V <= 0) VY_FAIL(VY_ERR_ARG, "vy_xent_fwd: bad arguments");
+  const int vec = dtype == VY_BF16 ? 8 : 4;
+  if (ld % vec || ld < vy_cdiv(V, vec) * vec) VY_FAIL(VY_ERR_ARG, "vy_xent_fwd: row stride must be a multiple of %d and cover the padded row", vec);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16) hipLaunchKernelGGL(xent_fwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, st, (const bf16*)logits, ld, labels, ignore_index, lse, loss_sum, count, (int)V);
+  else if (dtype == VY_F32) hipLaunchKernelGGL(xent_fwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)logits, ld, labels, ignore_index, lse, loss_sum, count, (int)V);
+  else VY_FAIL(VY_ERR_ARG, "vy_xent_fwd: bad dtype %d", dtype);
+  VY_CHECK_LAUNCH("vy_xent_fwd");
+  return VY_OK;
+}
+
+extern "C" int vy_xent_bwd(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, const float* lse,
+                           const float* gscale, const float* count, int64_t M, int64_t V, int dtype, void* stream) {
+  if (!logits || !labels || !lse || !gscale || !count || M <= 0 || V <= 0) VY_FAIL(VY_ERR_ARG, "vy_xent_bwd: bad arguments");
+  const int vec = dtype == VY_BF16 ? 8 : 4;
+  if (ld % vec || ld < vy_cdiv(V, vec) * vec) VY_FAIL(VY_ERR_ARG, "vy_xent_bwd: row stride must be a multiple of %d and cover the padded row", vec);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16) hipLaunchKernelGGL(xent_bwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, st, (bf16*)logits, ld, labels, ignore_index, lse, gscale, count, (int)V);
+  else if (dtype == VY_F32) hipLaunchKernelGGL(xent_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (float*)logits, ld, labels, ignore_index, lse, gscale, count, (int)V);
+  else VY_FAIL(VY_ERR_ARG, "vy_xent_bwd: bad dtype %d", dtype);
+  VY_CHECK_LAUNCH("vy_xent_bwd");
   return VY_OK;
 }
 

@@ -42,6 +42,15 @@ class LMHead(nn.Module):
         return ops.linear(x, _shadow(self.decoder.weight, dt), _shadow(self.bias, dt))
 
 
+    def loss(self, hidden_state: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+        """Shifted CLM cross-entropy fused with the head (no fp32 logits copy): the training-side
+        entry point; see autograd_train.LMHeadLossFn."""
+        from ..autograd_train import LMHeadLossFn
+        return LMHeadLossFn.apply(hidden_state, labels, ignore_index, self.dense.weight, self.dense.bias,
+                                  self.layer_norm.weight, self.layer_norm.bias, self.decoder.weight, self.bias,
+                                  self.layer_norm.eps)
+
+
 class PositionMixin:
     """Builds position embeddings / the RoPE angle table exactly like the reference constructors
     (models/decoder.py:294-304) and serves per-forward windows."""
@@ -55,11 +64,19 @@ class PositionMixin:
             self._rope_table = RopeTable(self.emb_freq)
             print(f"{who} Ignoring sinusoidal or absolute position embeddings because rope,is enable")
 
+    # fp32 master weights with bf16 kernels: set by FlatTrainer (None = the parameters' dtype)
+    compute_dtype = None
+
+    def _cast(self, hidden_state: torch.Tensor) -> torch.Tensor:
+        cd = self.compute_dtype
+        return hidden_state if cd is None or hidden_state.dtype == cd else hidden_state.to(cd)
+
     def _positions(self, hidden_state: torch.Tensor, start_pos: int, seqlen: int):
-        """-> (hidden_state [+ position info], freqs)."""
+        """-> (hidden_state [+ position info] in the compute dtype, freqs)."""
         if self.position_embeddings is not None:
             pos = self.position_embeddings(start_pos + seqlen)[:, start_pos:start_pos + seqlen, :]
-            return hidden_state + pos.to(device=hidden_state.device, dtype=hidden_state.dtype), None
+            return self._cast(hidden_state + pos.to(device=hidden_state.device, dtype=hidden_state.dtype)), None
+        hidden_state = self._cast(hidden_state)
         if start_pos + seqlen > self.emb_freq.shape[1]:
             raise ValueError(f"position {start_pos + seqlen} exceeds max_position_embeddings {self.emb_freq.shape[1]}")
         return hidden_state, RopeSlice(self._rope_table, start_pos, seqlen)

@@ -97,8 +97,9 @@ class DecoderModel(nn.Module, PositionMixin):
         self.lm_head = LMHead(config=config)
         self.config = config
 
-    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                use_cache: Optional[bool] = False, kv_cache=None, start_pos: Optional[int] = 0) -> CLMOutput:
+    def forward_hidden(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                       use_cache: Optional[bool] = False, kv_cache=None, start_pos: Optional[int] = 0):
+        """Everything of forward() up to the LM head -> (hidden_state, kv_cache)."""
         _bsz, seqlen = input_ids.shape
         hidden_state = self.word_embeddings(input_ids)
         hidden_state, freqs = self._positions(hidden_state, start_pos, seqlen)
@@ -109,6 +110,18 @@ class DecoderModel(nn.Module, PositionMixin):
         for layer in self.all_layer:
             hidden_state, kv_cache = layer(hidden_state, mask, freqs=freqs, use_cache=use_cache,
                                            kv_cache=kv_cache, start_pos=start_pos)
+        return hidden_state, kv_cache
+
+    def clm_loss(self, input_ids: torch.Tensor, labels: torch.Tensor,
+                 attention_mask: Optional[torch.Tensor] = None, ignore_index: int = -100) -> torch.Tensor:
+        """Shifted next-token loss (Examples/vyom-ai-decoder_clm.ipynb cell 29) with the LM head and
+        the cross-entropy fused (no logits copy)."""
+        hidden_state, _ = self.forward_hidden(input_ids, attention_mask)
+        return self.lm_head.loss(hidden_state, labels, ignore_index)
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                use_cache: Optional[bool] = False, kv_cache=None, start_pos: Optional[int] = 0) -> CLMOutput:
+        hidden_state, kv_cache = self.forward_hidden(input_ids, attention_mask, use_cache, kv_cache, start_pos)
         logits = self.lm_head(hidden_state)
         return CLMOutput(hidden_state=hidden_state, logits=logits, kv_cache=kv_cache)
 
@@ -144,7 +157,7 @@ class DecoderModel(nn.Module, PositionMixin):
         if use_cache:
             if use_static_cache:
                 kv_cache = StaticCacheOne(self.config, max_cache_len=total, batch_size=bsz,
-                                          dtype=self.word_embeddings.weight.dtype)
+                                          dtype=self.compute_dtype or self.word_embeddings.weight.dtype)
             else:
                 kv_cache = DynamicCacheOne(self.config)
         prev_pos = 0

@@ -268,3 +268,30 @@ def cast(src: Tensor, dst: Tensor) -> Tensor:
     _need_gpu(src, dst)
     call("vy_cast", src.data_ptr(), dst.data_ptr(), src.numel(), dtype_code(src.dtype), dtype_code(dst.dtype), _stream())
     return dst
+
+
+def act_bwd(dy: Tensor, pre: Tensor, act: int) -> Tensor:
+    """dy * act'(pre).  (vy_act_bwd)"""
+    _need_gpu(dy, pre)
+    d2, p2 = _rows(dy), _rows(pre)
+    M, N = p2.shape
+    out = torch.empty((M, N), dtype=dy.dtype, device=dy.device)
+    call("vy_act_bwd", d2.data_ptr(), d2.stride(0), p2.data_ptr(), p2.stride(0), out.data_ptr(), out.stride(0),
+         M, N, act, dtype_code(dy.dtype), _stream())
+    return out.view(pre.shape)
+
+
+def xent_fwd(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, loss_sum: Tensor, count: Tensor) -> None:
+    """logits2d: (M, V) view with 16-byte aligned, padded rows; labels int64 (M,)."""
+    _need_gpu(logits2d, labels, lse, loss_sum, count)
+    M, V = logits2d.shape
+    call("vy_xent_fwd", logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), ignore_index, lse.data_ptr(),
+         loss_sum.data_ptr(), count.data_ptr(), M, V, dtype_code(logits2d.dtype), _stream())
+
+
+def xent_bwd_(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, gscale: Tensor, count: Tensor) -> None:
+    """Overwrite logits with d loss / d logits (in place)."""
+    _need_gpu(logits2d, labels, lse, gscale, count)
+    M, V = logits2d.shape
+    call("vy_xent_bwd", logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), ignore_index, lse.data_ptr(),
+         gscale.data_ptr(), count.data_ptr(), M, V, dtype_code(logits2d.dtype), _stream())
