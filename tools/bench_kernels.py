@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--L", type=int, default=512)
+    ap.add_argument("--only", default="")
     a = ap.parse_args()
     B, L, d, h, dh = a.B, a.L, 768, 12, 64
     M = B * L
@@ -40,6 +41,8 @@ def main():
     for name, N, K, act, res in (("qkv(plain)", 2304, 768, 0, False), ("out+res", 768, 768, 0, True),
                                  ("ffn1+gelu", 3072, 768, 1, False), ("ffn2+res", 768, 3072, 0, True),
                                  ("lm_dense", 768, 768, 1, False)):
+        if a.only and a.only not in name:
+            continue
         xx = r(M, K)
         w = (r(N, K) / math.sqrt(K)).contiguous()
         b = r(N)
@@ -48,6 +51,10 @@ def main():
         t = timeit(lambda: ops.linear(xx, w, b, act=act, residual=rs, out=out), a.iters)
         fl = 2.0 * M * N * K
         rows.append((name, t, fl / t * 1e-6))
+    if a.only:
+        for n, t, f in rows:
+            print(f"{n:40s} {t:10.1f} us   {f:10.1f} TFLOP/s|GB/s")
+        return
     # lm head vocab projection
     w = (r(50265, 768) / 27.7).contiguous()
     b = r(50265)

@@ -58,6 +58,32 @@ __device__ __forceinline__ float vy_gelu_tanh_grad(float x) {
   const float t = tanhf(u);
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
 }
+// bf16-path GELU: erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below a bf16 ulp) --
+// one rcp, one exp2, five fma instead of ocml's erff; the exponential exp(-x^2/2) is shared
+// with the Gaussian factor of the derivative.
+__device__ __forceinline__ void vy_phi_fast(float x, float& cdf, float& gauss) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  gauss = __expf(-ax * ax);  // exp(-x^2/2)
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const float erf_abs = 1.0f - poly * t * gauss;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float vy_gelu_erf_fast(float x) {
+  float cdf, g;
+  vy_phi_fast(x, cdf, g);
+  return x * cdf;
+}
+__device__ __forceinline__ float vy_gelu_erf_grad_fast(float x) {
+  float cdf, g;
+  vy_phi_fast(x, cdf, g);
+  return cdf + x * 0.39894228040143267794f * g;
+}
+
 template <int ACT>
 __device__ __forceinline__ float vy_act_fwd(float x) {
   if constexpr (ACT == VY_ACT_GELU_ERF) return vy_gelu_erf(x);
@@ -80,6 +106,18 @@ __device__ __forceinline__ float vy_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// reduced-cost variants for bf16 storage (results are rounded to 8 bits of mantissa anyway)
+template <int ACT>
+__device__ __forceinline__ float vy_act_fwd_fast(float x) {
+  if constexpr (ACT == VY_ACT_GELU_ERF) return vy_gelu_erf_fast(x);
+  else return vy_act_fwd<ACT>(x);
+}
+template <int ACT>
+__device__ __forceinline__ float vy_act_grad_fast(float x) {
+  if constexpr (ACT == VY_ACT_GELU_ERF) return vy_gelu_erf_grad_fast(x);
+  else return vy_act_grad<ACT>(x);
 }
 
 // Round an fp32 value to bf16 and back.  Goes through the bit pattern: clang evaluates __bf16

@@ -19,6 +19,7 @@
 //
 // Reference semantics: nn.Linear call sites listed in include/vyom_hip.h.
 #include "vy_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -111,6 +112,7 @@ struct EpiQkv {
   int L; int nq; int nkv;  // nq = h*dh, nkv = hk*dh
   int dh;
   int rope;  // 1: fused rotary (requires dh == 64, wave n-tile == one head)
+  int vec8;  // dh % 8 == 0 and 16-byte aligned destinations: phase 2 may store 8 elements at once
 };
 
 template <typename T>
@@ -188,15 +190,191 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 constexpr int BK = 64;            // k elements per stage
 constexpr int ROWB = BK * 2;      // bytes per LDS row (128)
 
-template <int TM, int TN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
-__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
+// ---- shared epilogue of the bf16 kernels ------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM / (32 * WGM)], char* smem,
+                                              int m0, int n0, int M, int N, const EpiPlain<bf16>& ep,
+                                              const EpiQkv<bf16>& eq) {
+  constexpr int NW = WGM * WGN, NT = 64 * NW;
+  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+  constexpr int EROW = BN * 2 + 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int fr = lane & 31, fh = lane >> 5;
+  // Phase 1 (registers -> LDS): a lane owns output row m and, per register quad rg, the 4
+  // consecutive columns nb + 8*rg + 4*fh + (0..3): bias / activation are applied there and the
+  // bf16 tile is staged in LDS (rows padded by 16 B: 2-way on ds_write_b64 at worst).
+  // Phase 2 (LDS -> HBM): the whole workgroup walks the tile in 16-byte chunks, one wave
+  // instruction = whole rows, so residual / GELU' / RoPE operands are loaded and the output is
+  // stored as full 128-byte lines (a row-per-lane store tail is store-issue bound, ~10x slower).
+  constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
+  char* et = smem;
+
+  auto stage_quad = [&](int row, int col, const float (&v)[4]) {
+    bf16x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (bf16)v[e];
+    *reinterpret_cast<bf16x4*>(et + row * EROW + col * 2) = w;
+  };
+  // bias of a register quad (depends on the lane half only); loaded at use, not kept live
+  const bf16* biasp = EPI == 0 ? ep.bias : eq.bias;
+  const bool bias_vec = (reinterpret_cast<uintptr_t>(biasp) & 7) == 0;
+  auto bias_quad = [&](int n, float (&bq)[4]) {
+    if (biasp && n + 3 < N && bias_vec) {
+      const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(biasp + n);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bq[e] = (float)b4[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bq[e] = (biasp && n + e < N) ? (float)biasp[n + e] : 0.f;
+    }
+  };
+
+  if constexpr (EPI == 0) {
+    auto flush_plain = [&](bf16* __restrict__ dst, bool final_pass) {
+      for (int c = tid; c < BM * CPR; c += NT) {
+        const int row = c / CPR, cc = c - row * CPR;
+        const int64_t m = m0 + row;
+        const int n = n0 + cc * 8;
+        if (m >= M || n >= N) continue;
+        const bf16x8 sv = *reinterpret_cast<const bf16x8*>(et + row * EROW + cc * 16);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)sv[e];
+        if (ep.vec_ok && n + 8 <= N) {
+          if (final_pass) {
+            if constexpr (GRAD) {
+              if (ep.gradpre) {
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(ep.gradpre + m * ep.ldg + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= vy_act_grad_fast<ACT>((float)g[e]);
+              }
+            }
+            if (ep.residual) {
+              const bf16x8 r = *reinterpret_cast<const bf16x8*>(ep.residual + m * ep.ldr + n);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+            }
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+          *reinterpret_cast<bf16x8*>(dst + m * ep.ldy + n) = o;
+        } else {
+          for (int e = 0; e < 8 && n + e < N; ++e) {
+            float x = v[e];
+            if (final_pass) {
+              if constexpr (GRAD) {
+                if (ep.gradpre) x *= vy_act_grad_fast<ACT>((float)ep.gradpre[m * ep.ldg + n + e]);
+              }
+              if (ep.residual) x += (float)ep.residual[m * ep.ldr + n + e];
+            }
+            dst[m * ep.ldy + n + e] = (bf16)x;
+          }
+        }
+      }
+    };
+    const int passes = ep.pre ? 2 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+      const bool final_pass = pass == passes - 1;
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float bq[4];
+          bias_quad(n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, bq);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[i][j][4 * rg + e] + bq[e];
+              if constexpr (!GRAD) { if (final_pass) v[e] = vy_act_fwd_fast<ACT>(v[e]); }
+            }
+            stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
+            // keep the activation of one quad from being interleaved with the next ones: the
+            // unrolled erf/tanh chains otherwise cost >256 VGPRs and spill
+            if constexpr (ACT != VY_ACT_NONE && !GRAD) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      __syncthreads();
+      flush_plain(final_pass ? ep.y : ep.pre, final_pass);
+      if (!final_pass) __syncthreads();
+    }
+  } else {
+    // QKV: bias in registers; RoPE and the head-split scatter in phase 2, where a rotary pair
+    // (d, d+32) is two 16-byte chunks 64 bytes apart in the same staged row.  The staged values
+    // are the bf16-rounded projections, so the rotation reproduces the reference's op order
+    // (Linear output in q.dtype, then q*cos + rotate_half(q)*sin with every op rounded:
+    // VyomAI/layers/positional_embeddings.py:173-181) exactly.
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float bq[4];
+        bias_quad(n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, bq);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] + bq[e];
+          stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
+        }
+      }
+    __syncthreads();
+    for (int c = tid; c < BM * CPR; c += NT) {
+      const int row = c / CPR, cc = c - row * CPR;
+      const int64_t m = m0 + row;
+      const int n = n0 + cc * 8;
+      if (m >= M || n >= N) continue;
+      const int64_t b = m / eq.L, l = m - b * eq.L;
+      bf16x8 sv = *reinterpret_cast<const bf16x8*>(et + row * EROW + cc * 16);
+      if (eq.rope && n < eq.nq + eq.nkv) {
+        // dh == 64 and BN % 64 == 0: the partner chunk (d ^ 32) is in this tile row
+        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(et + row * EROW + (cc ^ 4) * 16);
+        const int d = n & 31;
+        const bool hi = (n & 32) != 0;
+        const float* cp = eq.cos_tab + (eq.pos0 + l) * 32 + d;
+        const float* sp = eq.sin_tab + (eq.pos0 + l) * 32 + d;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float cs = vy_round_bf16(cp[e]), sn = vy_round_bf16(sp[e]);
+          const float a = (float)sv[e], o = (float)pv[e];
+          const float t1 = vy_round_bf16(a * cs);
+          const float t2 = vy_round_bf16((hi ? o : -o) * sn);
+          sv[e] = (bf16)(t1 + t2);
+        }
+      }
+      if (eq.vec8) {
+        *reinterpret_cast<bf16x8*>(qkv_dest(eq, b, l, n)) = sv;
+      } else {
+        for (int e = 0; e < 8 && n + e < N; ++e) *qkv_dest(eq, b, l, n + e) = sv[e];
+      }
+    }
+  }
+}
+
+// tile BM x BN x 64 with WGM x WGN waves, each owning a (BM/WGM) x (BN/WGN) sub-tile as
+// TN x TM blocks of 32x32.  Shapes in use:
+//   256 x 192, 4x2 waves (512 threads, 1 workgroup per CU, 112 KiB LDS): the training shapes.  Loads
+//       per FLOP are (BM+BN)/(BM*BN) = 9.1 B/kFLOP -- a 128^2 tile needs 15.6 and is bound by the
+//       ~70 GB/s a CU can pull from L2, not by MFMA; 192 columns make N in {768, 2304, 3072} with
+//       M = 16384 give 256 / 768 / 1024 tiles, whole multiples of the 256 CUs;
+//   128 x 128, 2x2 waves (2 workgroups per CU): mid-size M;   32 x 128, 1x4 waves: skinny M.
+template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
     int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
-  static_assert(WGM * WGN == 4, "4 waves");
-  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-  constexpr int GX = BM / 8 / 4, GW = BN / 8 / 4;  // 8-row LDS-DMA pieces per wave per stage
+  constexpr int NW = WGM * WGN, NT = 64 * NW;
+  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+  static_assert(TM * 32 * WGM == BM && TN * 32 * WGN == BN, "tile / wave layout mismatch");
+  constexpr int PX = BM / 8, PW = BN / 8;               // 1-KiB LDS-DMA pieces (8 rows) per stage
+  constexpr int GX = (PX + NW - 1) / NW, GW = (PW + NW - 1) / NW;
   constexpr int STAGE = (BM + BN) * ROWB;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr int EROW = BN * 2 + 16;                     // epilogue tile row (padded)
+  constexpr int LDS_BYTES = 2 * STAGE > BM * EROW ? 2 * STAGE : BM * EROW;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,7 +389,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
   const bf16* wsrc[GW]; int wk[GW];
 #pragma unroll
   for (int t = 0; t < GX; ++t) {
-    const int R = (wave * GX + t) * 8 + lrow;
+    const int R = (wave + NW * t) * 8 + lrow;
     const int g = slot ^ ((R >> 1) & 7);
     int gm = m0 + R; gm = gm < M ? gm : M - 1;
     xsrc[t] = X + (int64_t)gm * ldx + g * 8;
@@ -219,7 +397,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
   }
 #pragma unroll
   for (int t = 0; t < GW; ++t) {
-    const int R = (wave * GW + t) * 8 + lrow;
+    const int R = (wave + NW * t) * 8 + lrow;
     const int g = slot ^ ((R >> 1) & 7);
     int gn = n0 + R; gn = gn < N ? gn : N - 1;
     wsrc[t] = W + (int64_t)gn * ldw + g * 8;
@@ -235,17 +413,21 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
     const int k0 = kt * BK;
 #pragma unroll
     for (int t = 0; t < GX; ++t) {
-      const bf16* s = xsrc[t] + k0;
-      if (ktail && k0 + xk[t] >= K) s = zero;
-      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
-                                       (VY_LDS void*)(xb + (wave * GX + t) * 1024), 16, 0, 0);
+      if (PX % NW == 0 || wave + NW * t < PX) {
+        const bf16* s = xsrc[t] + k0;
+        if (ktail && k0 + xk[t] >= K) s = zero;
+        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
+                                         (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, 0, 0);
+      }
     }
 #pragma unroll
     for (int t = 0; t < GW; ++t) {
-      const bf16* s = wsrc[t] + k0;
-      if (ktail && k0 + wk[t] >= K) s = zero;
-      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
-                                       (VY_LDS void*)(wb + (wave * GW + t) * 1024), 16, 0, 0);
+      if (PW % NW == 0 || wave + NW * t < PW) {
+        const bf16* s = wsrc[t] + k0;
+        if (ktail && k0 + wk[t] >= K) s = zero;
+        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
+                                         (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -266,70 +448,229 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(
   __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0)
   __syncthreads();
 
+  // fragments are double-buffered in registers: the reads of k-step ks+1 are issued before the
+  // MFMAs of k-step ks, so the LDS latency is exposed once per 64-wide tile, not four times
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](int buf, int ks, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    const char* xb = smem + buf * STAGE;
+    const char* wb = xb + BM * ROWB;
+    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+      w_[i] = *reinterpret_cast<const bf16x8*>(wb + wrow_off + i * 32 * ROWB + coff);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+      x_[j] = *reinterpret_cast<const bf16x8*>(xb + xrow_off + j * 32 * ROWB + coff);
+  };
+  read_frags(0, 0, wf[0], xf[0]);
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
-    const char* xb = smem + cur * STAGE;
-    const char* wb = xb + BM * ROWB;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int coff = (((ks * 2 + fh) ^ fsw) << 4);
-      bf16x8 wf[TN], xf[TM];
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        wf[i] = *reinterpret_cast<const bf16x8*>(wb + wrow_off + i * 32 * ROWB + coff);
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        xf[j] = *reinterpret_cast<const bf16x8*>(xb + xrow_off + j * 32 * ROWB + coff);
+      if (ks < 3) read_frags(cur, ks + 1, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
+    if (kt + 1 < KT) read_frags(cur ^ 1, 0, wf[0], xf[0]);
   }
+  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
+}
 
-  // ---- epilogue: lane owns row m, register quad rg owns columns nb + 8*rg + 4*fh + (0..3) ----
+// ------------------------------------------------------------------------------------------
+// deep-pipelined variant for the large-M (training) shapes: 256 x BN tile, 8 waves (4 x 2),
+// k-slices of 32 staged by LDS-DMA into a 4-deep LDS ring.  Three slices are always in flight:
+// a slice is waited for with a COUNTED vmcnt three iterations after it was issued, one raw
+// s_barrier per slice (no vmcnt(0) drain anywhere in the loop), so the L2 -> LDS latency is
+// covered by three slices of MFMA work instead of stalling every iteration.
+// LDS image of a slice: [rows][32] bf16 (64-byte rows), 16-byte chunk index XOR (row>>2)&3 on the
+// LDS-DMA source address and on the ds_read_b128: conflict-free for the 16-lane read groups.
+// ------------------------------------------------------------------------------------------
+#define VY_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int BN, int EPI, int ACT, bool GRAD, int VAR>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+  constexpr int BM = 256, WGM = 4, WGN = 2, NW = 8;
+  constexpr int TM = 2, TN = BN / 64;
+  constexpr int RK = 32, RROW = 64, NS = 4;
+  constexpr int PX = BM / 16, PW = BN / 16;          // 1-KiB pieces (16 rows x 64 B) per slice
+  constexpr int GX = PX / NW, GW = (PW + NW - 1) / NW;  // per wave: 2 and 2 (the last may be absent)
+  constexpr int STAGE = (BM + BN) * RROW;
+  constexpr int EROW = BN * 2 + 16;
+  constexpr int LDS_BYTES = NS * STAGE > BM * EROW ? NS * STAGE : BM * EROW;
+  static_assert(PX % NW == 0, "X pieces must divide over the waves");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lrow = lane >> 2, slot = lane & 3;
+  const bf16* xsrc[GX]; int xk[GX];
+  const bf16* wsrc[GW]; int wk[GW];
 #pragma unroll
-  for (int j = 0; j < TM; ++j) {
-    const int64_t m = m0 + wm * 32 * TM + j * 32 + fr;
-    if (m >= M) continue;
-    if constexpr (EPI == 0) {
+  for (int t = 0; t < GX; ++t) {
+    const int R = (wave + NW * t) * 16 + lrow;
+    const int g = slot ^ ((R >> 2) & 3);
+    int gm = m0 + R; gm = gm < M ? gm : M - 1;
+    xsrc[t] = X + (int64_t)gm * ldx + g * 8;
+    xk[t] = g * 8;
+  }
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          float v[4] = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
-          epi_plain_quad<bf16, ACT, GRAD>(ep, v, m, n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, N);
-        }
+  for (int t = 0; t < GW; ++t) {
+    const int R = (wave + NW * t) * 16 + lrow;
+    const int g = slot ^ ((R >> 2) & 3);
+    int gn = n0 + R; gn = gn < N ? gn : N - 1;
+    wsrc[t] = W + (int64_t)gn * ldw + g * 8;
+    wk[t] = g * 8;
+  }
+  // LDS-DMA instructions this wave issues per slice (wave-uniform): all X pieces + its W pieces
+  const bool w_last = (PW % NW == 0) || (wave + NW * (GW - 1) < PW);
+  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
+  const bool ktail = (K % RK) != 0;
+  const int KT = (K + RK - 1) / RK;
+
+  // one LDS-DMA piece of slice kt: pieces 0..GX-1 are X, GX..GX+GW-1 are W
+  auto stage_piece = [&](int kt, int pc) {
+    char* xb = smem + (kt & (NS - 1)) * STAGE;
+    char* wb = xb + BM * RROW;
+    const int k0 = kt * RK;
+    if (pc < GX) {
+      const bf16* s = xsrc[pc] + k0;
+      if (ktail && k0 + xk[pc] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
+                                       (VY_LDS void*)(xb + (wave + NW * pc) * 1024), 16, 0, 0);
     } else {
-      bool did_rope = false;
-      if constexpr (TN % 2 == 0) {  // rotary pairs need a 64-wide (one head) wave tile
-        if (eq.rope) {
-          did_rope = true;
-#pragma unroll
-          for (int i = 0; i < TN; i += 2)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            float lo[4] = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
-            float hi[4] = {acc[i + 1][j][4 * rg], acc[i + 1][j][4 * rg + 1], acc[i + 1][j][4 * rg + 2], acc[i + 1][j][4 * rg + 3]};
-            epi_qkv_pair<bf16>(eq, lo, hi, m, n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, N);
-          }
-        }
+      const int t = pc - GX;
+      if (t < GW - 1 || w_last) {
+        const bf16* s = wsrc[t] + k0;
+        if (ktail && k0 + wk[t] >= K) s = zero;
+        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
+                                         (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
       }
-      if (!did_rope) {
+    }
+  };
+  auto stage = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+    for (int pc = 0; pc < GX + GW; ++pc) stage_piece(kt, pc);
+  };
+
+  f32x16 acc[TN][TM];
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            float v[4] = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
-            epi_qkv_quad<bf16>(eq, v, m, n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, N);
-          }
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+  const int xrow_off = (wm * 32 * TM + fr) * RROW;
+  const int wrow_off = (wn * 32 * TN + fr) * RROW;
+
+  auto wait_landed = [&](int younger) {  // all but the loads of `younger` later slices are done
+    if (w_last) {
+      if (younger >= 2) VY_WAIT_VM(8); else if (younger == 1) VY_WAIT_VM(4); else VY_WAIT_VM(0);
+    } else {
+      if (younger >= 2) VY_WAIT_VM(6); else if (younger == 1) VY_WAIT_VM(3); else VY_WAIT_VM(0);
+    }
+  };
+  auto read_frags = [&](int kt, int ks, bf16x8 (&wf)[TN], bf16x8 (&xf)[TM]) {
+    const char* xb = smem + (kt & (NS - 1)) * STAGE;
+    const char* wb = xb + BM * RROW;
+    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+      wf[i] = *reinterpret_cast<const bf16x8*>(wb + wrow_off + i * 32 * RROW + coff);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+      xf[j] = *reinterpret_cast<const bf16x8*>(xb + xrow_off + j * 32 * RROW + coff);
+  };
+  auto mma = [&](bf16x8 (&wf)[TN], bf16x8 (&xf)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+  };
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < KT) stage(s);
+
+  if constexpr (VAR == 0) {
+    for (int kt = 0; kt < KT; ++kt) {
+      wait_landed(min(2, KT - 1 - kt));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NS - 1 < KT) stage(kt + NS - 1);  // refills the buffer every wave finished reading
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 wf[TN], xf[TM];
+        read_frags(kt, ks, wf, xf);
+        mma(wf, xf);
+      }
+    }
+  } else if constexpr (VAR == 1) {
+    // MFMAs first: the matrix pipe starts right after the barrier, the LDS-DMA issue of the
+    // slice three ahead rides in the shadow of the first k-step's MFMAs
+    for (int kt = 0; kt < KT; ++kt) {
+      wait_landed(min(2, KT - 1 - kt));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      bf16x8 wf[TN], xf[TM], wf1[TN], xf1[TM];
+      read_frags(kt, 0, wf, xf);
+      read_frags(kt, 1, wf1, xf1);
+      __builtin_amdgcn_s_setprio(1);
+      mma(wf, xf);
+      __builtin_amdgcn_s_setprio(0);
+      if (kt + NS - 1 < KT) stage(kt + NS - 1);
+      __builtin_amdgcn_s_setprio(1);
+      mma(wf1, xf1);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  } else {
+    // VAR 2: software-pipelined fragments: the first k-step's fragments of slice kt+1 are read at
+    // the end of iteration kt (slice kt+1 is known landed one iteration early), so every barrier
+    // is followed immediately by MFMAs; LDS-DMA pieces are spread between the MFMA groups.
+    bf16x8 wf[TN], xf[TM], wf1[TN], xf1[TM];
+    // simple, safe prologue: everything issued so far except the youngest slice has landed
+    if (KT >= 3) { wait_landed(1); } else { wait_landed(0); }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, wf, xf);
+    for (int kt = 0; kt < KT; ++kt) {
+      read_frags(kt, 1, wf1, xf1);
+      if (kt + NS - 1 < KT) { stage_piece(kt + NS - 1, 0); stage_piece(kt + NS - 1, 1); }
+      __builtin_amdgcn_s_setprio(1);
+      mma(wf, xf);
+      __builtin_amdgcn_s_setprio(0);
+      if (kt + NS - 1 < KT) { stage_piece(kt + NS - 1, 2); stage_piece(kt + NS - 1, 3); }
+      if (kt + 1 < KT) read_frags(kt + 1, 0, wf, xf);  // slice kt+1 landed before this iteration
+      __builtin_amdgcn_s_setprio(1);
+      mma(wf1, xf1);
+      __builtin_amdgcn_s_setprio(0);
+      // before the next iteration: slice kt+2 must have landed (only slice kt+3 may be in flight)
+      if (kt + 1 < KT) {
+        wait_landed(kt + 3 < KT ? 1 : 0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
       }
     }
   }
+  __syncthreads();  // every wave is done with the ring before the epilogue reuses the LDS
+  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -401,12 +742,37 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
                 int64_t K, const EpiPlain<bf16>& ep, const EpiQkv<bf16>& eq, hipStream_t st) {
   if (M <= 32) {  // skinny (decode): 32 x 128 tiles keep more workgroups in flight
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 32);
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<1, 1, 1, 4, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<32, 128, 1, 4, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
+                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+  } else if (M <= 1024) {
+    const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                        st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
   } else {
-    const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<2, 2, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
-                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    const int tn = (int)vy_cdiv(N, 192), tm = (int)vy_cdiv(M, 256);
+    // default: 2-stage 64-deep tiles.  256 x 192 divides N in {768, 2304} x M = 16384 into whole
+    // multiples of the 256 CUs; 256 x 256 (fewer L2 bytes per FLOP) where N is wide enough for
+    // whole rounds anyway (FFN1, vocabulary).  VY_GEMM_VARIANT selects the experimental ring
+    // kernels (0-2) or forces a tile (8/9) for A/B runs in one process.
+    static const int var = [] { const char* e = getenv("VY_GEMM_VARIANT"); return e ? atoi(e) : -1; }();
+    const bool wide = (N >= 3072);
+    if (var == 8 || (var < 0 && wide)) {
+      const int tn2 = (int)vy_cdiv(N, 256);
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq);
+    } else if (var == 9 || var < 0) {
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    } else if (var == 1) {
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 1>), dim3(tm * tn), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    } else if (var == 2) {
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 2>), dim3(tm * tn), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    } else {
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 0>), dim3(tm * tn), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    }
   }
   return 0;
 }
@@ -447,11 +813,11 @@ int linear_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const vo
   EpiPlain<T> ep;
   ep.bias = (const T*)bias; ep.residual = (const T*)residual; ep.ldr = ldr;
   ep.gradpre = (const T*)gradpre; ep.ldg = ldg; ep.y = (T*)y; ep.ldy = ldy; ep.pre = (T*)pre_out;
-  const size_t qa = 4 * sizeof(T);
-  ep.vec_ok = (ldy % 4 == 0) && aligned_to(y, qa) && (!bias || aligned_to(bias, qa)) &&
-              (!residual || (ldr % 4 == 0 && aligned_to(residual, qa))) &&
-              (!gradpre || (ldg % 4 == 0 && aligned_to(gradpre, qa))) &&
-              (!pre_out || aligned_to(pre_out, qa));
+  const int ve = 16 / (int)sizeof(T);  // elements per 16-byte access (bf16: 8, f32 quads: 4)
+  ep.vec_ok = (ldy % ve == 0) && aligned_to(y, 16) && (!bias || aligned_to(bias, 4 * sizeof(T))) &&
+              (!residual || (ldr % ve == 0 && aligned_to(residual, 16))) &&
+              (!gradpre || (ldg % ve == 0 && aligned_to(gradpre, 16))) &&
+              (!pre_out || aligned_to(pre_out, 16));
   EpiQkv<T> eq{};
 #define VY_GO(ACT_, GRAD_)                                                                              \
   do {                                                                                                  \
@@ -504,8 +870,13 @@ int qkv_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void*
   eq.v = (T*)v; eq.v_sb = v_sb; eq.v_sh = v_sh; eq.v_sl = v_sl;
   eq.L = (int)L; eq.nq = h * dh; eq.nkv = hk * dh; eq.dh = dh;
   // fused rotary: bf16 kernel with 64-wide wave tiles and dh == 64 (pairs are register-local)
-  const bool fuse = cos_tab && sizeof(T) == 2 && dh == 64 && M > 32;
+  const bool fuse = cos_tab && sizeof(T) == 2 && dh == 64;
   eq.rope = fuse ? 1 : 0;
+  {
+    bool v8 = dh % 8 == 0 && aligned_to(q, 16) && aligned_to(k, 16) && aligned_to(v, 16);
+    for (int64_t st_ : strides) v8 = v8 && (st_ % 8 == 0);
+    eq.vec8 = v8 ? 1 : 0;
+  }
   EpiPlain<T> ep{};
   if constexpr (sizeof(T) == 2)
     launch_bf16<1, VY_ACT_NONE, false>((const bf16*)x, ldx, (const bf16*)w, ldw, M, N, K,
