@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--attn", default="none", choices=["none", "gqa"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     return ap.parse_args()
 
 
@@ -187,12 +188,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # rehearsals with more ranks than GPUs share a device (gloo only)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     import vyomai_amd as V
     from vyomai_amd import recipe

@@ -201,6 +201,42 @@ int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t
 /* y = x converted between fp32 and bf16 (n elements). src_dtype -> dst_dtype. */
 int vy_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Native decode driver: one call runs a whole single-token step (L == 1) of the GPT-style
+ * decoder -- every layer's QKV+RoPE (K/V appended to the static cache in place), cached
+ * attention, out-projection + residual + LayerNorm, FFN + residual + LayerNorm, then the LM head
+ * -- as ~8 launches per layer with no host work in between.
+ * replaces: the per-token body of DecoderModel.generate / DecoderModel.forward for seqlen == 1
+ *   (VyomAI/models/decoder.py:343-374, 477-488) and DecoderLayer.forward (:222-250).
+ * All pointers are device pointers; weights are `dtype` (bf16 or f32) in nn.Linear layout.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const void *wqkv, *bqkv;          /* packed [(h+2hk)*dh, d], [(h+2hk)*dh] (bias may be NULL) */
+  const void *wo, *bo, *ln1_w, *ln1_b;
+  const void *w1, *b1, *w2, *b2, *ln2_w, *ln2_b;
+  void *kcache, *vcache;            /* (B, hk, cap, dh) */
+  int64_t c_sb, c_sh, c_sl;         /* cache element strides {batch, head, token} */
+} vy_decode_layer;
+
+typedef struct {
+  int32_t num_layers, B, d, h, hk, dh, ffn, vocab, act, dtype;
+  float eps_attn, eps_ffn, eps_head;
+  const float *cos_tab, *sin_tab;   /* NULL: no RoPE (additive position encodings) */
+  const vy_decode_layer* layers;    /* host array [num_layers] */
+  const void *head_wd, *head_bd, *head_ln_w, *head_ln_b, *head_wv, *head_bias;
+  void* ws; int64_t ws_bytes;       /* device workspace, >= vy_decode_ws_bytes(...) */
+} vy_decode_plan;
+
+int64_t vy_decode_ws_bytes(int32_t B, int32_t d, int32_t h, int32_t hk, int32_t dh, int32_t ffn,
+                           int32_t dtype);
+/* x: (B, d) input embeddings (+ position info); pos: index of this token (keys 0..pos are
+ * attended); hidden_out (nullable): (B, d) last hidden state; logits (nullable): (B, ldv).
+ * pos_dev (nullable): device int32 holding the position -- when given, every kernel reads the
+ * position on the device and `pos` is ignored, so one captured hipGraph of this call can be
+ * replayed for every token (bf16, head_dim 64 models). */
+int vy_decoder_step(const vy_decode_plan* plan, const void* x, int64_t pos, const int32_t* pos_dev,
+                    void* hidden_out, void* logits, int64_t ldv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

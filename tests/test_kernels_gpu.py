@@ -47,6 +47,7 @@ ACTS = {0: lambda x: x, 1: O.gelu_erf, 2: O.gelu_tanh}
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (51, 1003, 768), (300, 768, 72),
                                    (16, 768, 768), (1, 256, 3072), (1024, 3072, 768), (640, 768, 3072),
+                                   (32, 3072, 768), (32, 1003, 768), (7, 768, 3072), (32, 64, 40),
                                    # > 1024 rows: the 256 x 192 tile kernel (M / N / K tails)
                                    (2000, 768, 768), (4096, 1003, 768), (1500, 384, 72), (3072, 3072, 768)])
 @pytest.mark.parametrize("act", [0, 1])
@@ -96,6 +97,7 @@ def _qkv_ref(x, w, b, h, hk, dh, pos0, rope, dtype):
 @pytest.mark.parametrize("B,L,K,h,hk,dh,rope", [(2, 96, 768, 12, 4, 64, True), (2, 17, 64, 4, 2, 16, True),
                                                (3, 50, 768, 12, 12, 64, False), (2, 1, 768, 12, 4, 64, True),
                                                (1, 40, 256, 2, 1, 128, True), (4, 300, 768, 12, 4, 64, True),
+                                               (32, 1, 768, 12, 12, 64, True), (5, 1, 768, 12, 4, 64, False),
                                                (3, 700, 768, 12, 12, 64, True)])
 def test_qkv_rope(dtype, B, L, K, h, hk, dh, rope):
     ops, _ = _ops()

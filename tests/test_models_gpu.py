@@ -210,3 +210,20 @@ def test_modules_vs_golden(golden, tag):
                       full_freqs[:, L - 5:L], True, cache, L - 5)
             close(y0, g[f"{tag}.{name}.chunk0"], 1e-5, "chunk0")
             close(y1, g[f"{tag}.{name}.chunk1"], 1e-5, "chunk1")
+
+
+def test_decode_graph_replay_matches_eager(monkeypatch):
+    """bf16 greedy decode: the hipGraph-replayed native step (device-side position) produces the
+    same tokens as the eager per-kernel path and as plain re-forwarding without a cache."""
+    import vyomai_amd as V
+    cfg = cases.test_cfg()
+    m = build(V.DecoderModel, cfg, "rope", None, dtype=torch.bfloat16)
+    ids = T(recipe.token_ids("graph.ids", (4, 40), 3, cfg.vocab_size)).to(DEV)
+    am = torch.ones_like(ids)
+    monkeypatch.setenv("VY_DECODE_GRAPH", "1")
+    t_graph = m.generate(ids, am, max_len=12, use_cache=True, use_static_cache=True)
+    monkeypatch.setenv("VY_DECODE_GRAPH", "0")
+    t_eager = m.generate(ids, am, max_len=12, use_cache=True, use_static_cache=True)
+    t_dyn = m.generate(ids, am, max_len=12, use_cache=True, use_static_cache=False)
+    assert torch.equal(t_graph, t_eager)
+    assert torch.equal(t_graph, t_dyn)

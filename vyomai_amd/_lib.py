@@ -43,9 +43,10 @@ PROTOTYPES = {
     "vy_xent_fwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
     "vy_xent_bwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
     "vy_transpose": [_p, _i64, _p, _i64, _i64, _i64, _i, _p],
+    "vy_decoder_step": [_p, _p, _i64, _p, _p, _p, _i64, _p],
     "vy_cast": [_p, _p, _i64, _i, _i, _p],
 }
-OTHER_SYMBOLS = ["vy_last_error", "vy_abi_version", "vy_layernorm_bwd_ws_rows"]
+OTHER_SYMBOLS = ["vy_last_error", "vy_abi_version", "vy_layernorm_bwd_ws_rows", "vy_decode_ws_bytes"]
 ALL_SYMBOLS = list(PROTOTYPES) + OTHER_SYMBOLS
 
 
@@ -76,6 +77,8 @@ def load() -> C.CDLL:
     lib.vy_abi_version.restype = C.c_int
     lib.vy_layernorm_bwd_ws_rows.restype = C.c_int64
     lib.vy_layernorm_bwd_ws_rows.argtypes = [_i64]
+    lib.vy_decode_ws_bytes.restype = C.c_int64
+    lib.vy_decode_ws_bytes.argtypes = [C.c_int32] * 7
     _lib = lib
     return lib
 

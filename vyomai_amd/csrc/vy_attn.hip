@@ -39,6 +39,7 @@ struct AttnParams {
   const float* addmask; int64_t am_sb, am_sl;
   int B, h, hk, L, S;
   float scale;
+  const int* pos_dev;  // decode under a hipGraph: S = *pos_dev + 1 (else NULL)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -306,38 +307,56 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnParams p, int dh)
   const float* am = hasadd ? p.addmask + (int64_t)b * p.am_sb + (int64_t)qi * p.am_sl : nullptr;
   // pure causal: invisible keys contribute exactly 0 -> stop at the diagonal.  With key padding
   // every key is walked so a fully masked row reproduces the reference's uniform average.
-  int S_eff = p.S;
-  if (causal && !haskp && !hasadd) S_eff = min(p.S, qi + p.start_pos + 1);
+  int S_eff = p.pos_dev ? *p.pos_dev + 1 : p.S;
+  if (causal && !haskp && !hasadd) S_eff = min(S_eff, qi + p.start_pos + 1);
 
   float m = -FLT_MAX, l = 0.f, acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-  for (int j0 = wave * KPP; j0 < S_eff; j0 += 4 * KPP) {
-    const int j = j0 + grp;
-    const bool valid = j < S_eff;
-    const int jc = valid ? j : S_eff - 1;
-    float kv[VEC];
-    RowVec<T>::load(Kb + (int64_t)jc * p.k_sl + ch * VEC, kv);
-    float d = 0.f;
+  // U key groups per trip: their K and V chunks are all requested before the first dot product,
+  // so a wave keeps 2*U 16-byte loads in flight (decode is a pure HBM stream of the KV cache)
+  constexpr int U = 4;
+  for (int j0 = wave * KPP; j0 < S_eff; j0 += 4 * KPP * U) {
+    float kv[U][VEC], vv[U][VEC], t[U];
+    bool valid[U];
+    int jc[U];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) d = fmaf(qv[e], kv[e], d);
-#pragma unroll
-    for (int o_ = CPR >> 1; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
-    float t = d * p.scale;
-    if (hasadd) t = t + am[jc];
-    if (causal && jc > qi + p.start_pos) t = -FLT_MAX;
-    if (haskp && !kp[jc]) t = -FLT_MAX;
-    t = fmaxf(t, -FLT_MAX);
-    if (valid) {
-      const float mn = fmaxf(m, t);
-      const float a = __expf(m - mn), e_ = __expf(t - mn);
-      float vv[VEC];
-      RowVec<T>::load(Vb + (int64_t)jc * p.v_sl + ch * VEC, vv);
-      l = l * a + e_;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[e] = acc[e] * a + e_ * vv[e];
-      m = mn;
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * 4 * KPP + grp;
+      valid[u] = j < S_eff;
+      jc[u] = valid[u] ? j : S_eff - 1;
+      RowVec<T>::load(Kb + (int64_t)jc[u] * p.k_sl + ch * VEC, kv[u]);
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) RowVec<T>::load(Vb + (int64_t)jc[u] * p.v_sl + ch * VEC, vv[u]);
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) d = fmaf(qv[e], kv[u][e], d);
+#pragma unroll
+      for (int o_ = CPR >> 1; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
+      float x = d * p.scale;
+      if (hasadd) x = x + am[jc[u]];
+      if (causal && jc[u] > qi + p.start_pos) x = -FLT_MAX;
+      if (haskp && !kp[jc[u]]) x = -FLT_MAX;
+      x = fmaxf(x, -FLT_MAX);
+      t[u] = x;
+      if (valid[u]) mn = fmaxf(mn, x);
+    }
+    const float a = __expf(m - mn);
+    l *= a;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] *= a;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float e_ = valid[u] ? __expf(t[u] - mn) : 0.f;
+      l += e_;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = fmaf(e_, vv[u][e], acc[e]);
+    }
+    m = mn;
   }
   // combine the KPP key groups of the wave (lanes with equal ch), then the 4 waves through LDS
 #pragma unroll
@@ -430,7 +449,7 @@ extern "C" int vy_attn_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   p.out = out; p.o_sb = o_sb; p.o_sl = o_sl; p.lse = lse;
   p.mask_kind = mask_kind; p.start_pos = (int)start_pos;
   p.keypad = keypad; p.kp_sb = kp_sb; p.addmask = addmask; p.am_sb = am_sb; p.am_sl = am_sl;
-  p.B = (int)B; p.h = h; p.hk = hk; p.L = (int)L; p.S = (int)S; p.scale = scale;
+  p.B = (int)B; p.h = h; p.hk = hk; p.L = (int)L; p.S = (int)S; p.scale = scale; p.pos_dev = nullptr;
   if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
   if (int rc = check_attn(who, p, dh, dtype)) return rc;
   hipStream_t st = (hipStream_t)stream;
@@ -445,10 +464,23 @@ extern "C" int vy_attn_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   return launch_rowwise<float>(p, dh, st, who);
 }
 
+int vy_attn_decode_ex(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_sh,
+                      int64_t k_sl, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl, void* out,
+                      int64_t o_sb, int64_t B, int h, int hk, int64_t S, const int* pos_dev, int dh, float scale,
+                      int dtype, void* stream);
+
 extern "C" int vy_attn_decode(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb,
                               int64_t k_sh, int64_t k_sl, const void* v, int64_t v_sb, int64_t v_sh,
                               int64_t v_sl, void* out, int64_t o_sb, int64_t B, int h, int hk, int64_t S,
                               int dh, float scale, int dtype, void* stream) {
+  return vy_attn_decode_ex(q, q_sb, q_sh, k, k_sb, k_sh, k_sl, v, v_sb, v_sh, v_sl, out, o_sb, B, h, hk, S, nullptr,
+                           dh, scale, dtype, stream);
+}
+
+int vy_attn_decode_ex(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_sh,
+                      int64_t k_sl, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl, void* out,
+                      int64_t o_sb, int64_t B, int h, int hk, int64_t S, const int* pos_dev, int dh, float scale,
+                      int dtype, void* stream) {
   const char* who = "vy_attn_decode";
   AttnParams p{};
   p.q = q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = (int64_t)h * dh;  // single token: unused stride
@@ -456,7 +488,7 @@ extern "C" int vy_attn_decode(const void* q, int64_t q_sb, int64_t q_sh, const v
   p.v = v; p.v_sb = v_sb; p.v_sh = v_sh; p.v_sl = v_sl;
   p.out = out; p.o_sb = o_sb; p.o_sl = (int64_t)h * dh; p.lse = nullptr;
   p.mask_kind = VY_MASK_NONE; p.start_pos = 0;
-  p.B = (int)B; p.h = h; p.hk = hk; p.L = 1; p.S = (int)S; p.scale = scale;
+  p.B = (int)B; p.h = h; p.hk = hk; p.L = 1; p.S = (int)S; p.scale = scale; p.pos_dev = pos_dev;
   if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
   if (int rc = check_attn(who, p, dh, dtype)) return rc;
   hipStream_t st = (hipStream_t)stream;

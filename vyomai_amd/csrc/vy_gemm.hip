@@ -113,6 +113,7 @@ struct EpiQkv {
   int dh;
   int rope;  // 1: fused rotary (requires dh == 64, wave n-tile == one head)
   int vec8;  // dh % 8 == 0 and 16-byte aligned destinations: phase 2 may store 8 elements at once
+  const int* pos_dev;  // decode under a hipGraph: token position read on the device (else NULL)
 };
 
 template <typename T>
@@ -121,6 +122,7 @@ __device__ __forceinline__ T* qkv_dest(const EpiQkv<T>& e, int64_t b, int64_t l,
   if (n < e.nq) { const int hd = n / e.dh, d = n - hd * e.dh;
     return e.q + b * e.q_sb + hd * e.q_sh + l * e.q_sl + d; }
   n -= e.nq;
+  if (e.pos_dev) l += *e.pos_dev;  // K/V land at the cache slot of the current position
   if (n < e.nkv) { const int hd = n / e.dh, d = n - hd * e.dh;
     return e.k + b * e.k_sb + hd * e.k_sh + l * e.k_sl + d; }
   n -= e.nkv;
@@ -149,8 +151,9 @@ __device__ __forceinline__ void epi_qkv_pair(const EpiQkv<T>& e, float (&lo)[4],
     // (VyomAI/layers/positional_embeddings.py:173-181); products are formed on the
     // storage-rounded projection like the reference's separate Linear -> RoPE ops.
     const int d = n_lo & 31;  // head base is a multiple of 64, n_lo is in the low half
-    const float* cp = e.cos_tab + (e.pos0 + l) * 32 + d;
-    const float* sp = e.sin_tab + (e.pos0 + l) * 32 + d;
+    const int64_t pp = (e.pos_dev ? (int64_t)*e.pos_dev : e.pos0) + l;
+    const float* cp = e.cos_tab + pp * 32 + d;
+    const float* sp = e.sin_tab + pp * 32 + d;
     const f32x4 c4 = *reinterpret_cast<const f32x4*>(cp);
     const f32x4 s4 = *reinterpret_cast<const f32x4*>(sp);
 #pragma unroll
@@ -335,8 +338,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
         const bf16x8 pv = *reinterpret_cast<const bf16x8*>(et + row * EROW + (cc ^ 4) * 16);
         const int d = n & 31;
         const bool hi = (n & 32) != 0;
-        const float* cp = eq.cos_tab + (eq.pos0 + l) * 32 + d;
-        const float* sp = eq.sin_tab + (eq.pos0 + l) * 32 + d;
+        const int64_t pp = (eq.pos_dev ? (int64_t)*eq.pos_dev : eq.pos0) + l;
+        const float* cp = eq.cos_tab + pp * 32 + d;
+        const float* sp = eq.sin_tab + pp * 32 + d;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float cs = vy_round_bf16(cp[e]), sn = vy_round_bf16(sp[e]);
@@ -674,6 +678,99 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// skinny kernel for decode (M <= 32 rows): HBM-bound weight streaming, no LDS staging.
+// One workgroup = 32 output columns; its 4 waves split K (k-step s goes to wave s % 4, so the
+// four waves together consume whole 128-byte lines of every weight row), W and X fragments are
+// loaded straight into MFMA operand registers (each weight byte is used once per workgroup),
+// and the four partial 32x32 accumulators are summed through LDS.  With fused RoPE a workgroup
+// owns columns {d, d+32} of 16 rotary pairs of one head, so a pair sits in registers r and r+8
+// of one lane.
+// ------------------------------------------------------------------------------------------
+template <int EPI, int ACT>
+__global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+  __shared__ float red[3][16][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nb = blockIdx.x;
+  const bool rope_map = (EPI == 1) && eq.rope;
+  int col = nb * 32 + fr;
+  if (rope_map) col = (nb >> 1) * 64 + 16 * (nb & 1) + (fr < 16 ? fr : 16 + fr);
+  const int wr = col < N ? col : N - 1;
+  const int mr = fr < M ? fr : M - 1;
+  const bf16* wp = W + (int64_t)wr * ldw + fh * 8;
+  const bf16* xp = X + (int64_t)mr * ldx + fh * 8;
+  const int nsteps = K >> 4;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int s = wave;
+  // 12 k-steps of this wave per trip (K = 768 in one trip): 24 independent 16-byte loads are in
+  // flight before the first MFMA -- the kernel is a latency-bound HBM stream, not compute
+  for (; s + 44 < nsteps; s += 48) {
+    bf16x8 a[12], b[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      a[u] = *reinterpret_cast<const bf16x8*>(wp + 16 * (s + 4 * u));
+      b[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 4 * u));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all 24 loads are issued before the first MFMA waits
+#pragma unroll
+    for (int u = 0; u < 12; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; s + 12 < nsteps; s += 16) {
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const bf16x8*>(wp + 16 * (s + 4 * u));
+      b[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 4 * u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; s < nsteps; s += 4) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(wp + 16 * s);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+  const int64_t m = fr;
+  if (m >= M) return;
+  if constexpr (EPI == 0) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      float v[4] = {acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]};
+      epi_plain_quad<bf16, ACT, false>(ep, v, m, nb * 32 + 8 * rg + 4 * fh, N);
+    }
+  } else {
+    if (rope_map) {
+#pragma unroll
+      for (int rg = 0; rg < 2; ++rg) {
+        float lo[4] = {acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]};
+        float hi[4] = {acc[4 * rg + 8], acc[4 * rg + 9], acc[4 * rg + 10], acc[4 * rg + 11]};
+        epi_qkv_pair<bf16>(eq, lo, hi, m, (nb >> 1) * 64 + 16 * (nb & 1) + 8 * rg + 4 * fh, N);
+      }
+    } else {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float v[4] = {acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]};
+        epi_qkv_quad<bf16>(eq, v, m, nb * 32 + 8 * rg + 4 * fh, N);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // f32 MFMA kernel (parity path): 64x64 tile, BK=16, 4 waves of 32x32, mfma_f32_32x32x2f32
 // ------------------------------------------------------------------------------------------
 constexpr int FBK = 16;
@@ -740,7 +837,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
 template <int EPI, int ACT, bool GRAD>
 int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t M, int64_t N,
                 int64_t K, const EpiPlain<bf16>& ep, const EpiQkv<bf16>& eq, hipStream_t st) {
-  if (M <= 32) {  // skinny (decode): 32 x 128 tiles keep more workgroups in flight
+  if (M <= 32 && K % 16 == 0 && !GRAD && (EPI == 0 || !eq.rope || N % 64 == 0)) {
+    hipLaunchKernelGGL((gemm_skinny_bf16_kernel<EPI, ACT>), dim3((unsigned)vy_cdiv(N, 32)), dim3(256), 0, st, X, ldx,
+                       W, ldw, (int)M, (int)N, (int)K, ep, eq);
+  } else if (M <= 32) {  // skinny fallback: 32 x 128 tiles
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 32);
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<32, 128, 1, 4, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                        st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
@@ -849,7 +949,7 @@ int qkv_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void*
              const float* cos_tab, const float* sin_tab, int64_t pos0, void* q, int64_t q_sb,
              int64_t q_sh, int64_t q_sl, void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl, void* v,
              int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t L, int64_t K, int h, int hk,
-             int dh, hipStream_t st) {
+             int dh, hipStream_t st, const int* pos_dev = nullptr) {
   const char* who = "vy_qkv_rope_fwd";
   const int64_t M = B * L, N = (int64_t)(h + 2 * hk) * dh;
   if (int rc = check_operands<T>(who, x, ldx, w, ldw, M, N, K)) return rc;
@@ -868,7 +968,7 @@ int qkv_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void*
   eq.q = (T*)q; eq.q_sb = q_sb; eq.q_sh = q_sh; eq.q_sl = q_sl;
   eq.k = (T*)k; eq.k_sb = k_sb; eq.k_sh = k_sh; eq.k_sl = k_sl;
   eq.v = (T*)v; eq.v_sb = v_sb; eq.v_sh = v_sh; eq.v_sl = v_sl;
-  eq.L = (int)L; eq.nq = h * dh; eq.nkv = hk * dh; eq.dh = dh;
+  eq.L = (int)L; eq.nq = h * dh; eq.nkv = hk * dh; eq.dh = dh; eq.pos_dev = pos_dev;
   // fused rotary: bf16 kernel with 64-wide wave tiles and dh == 64 (pairs are register-local)
   const bool fuse = cos_tab && sizeof(T) == 2 && dh == 64;
   eq.rope = fuse ? 1 : 0;
@@ -886,6 +986,7 @@ int qkv_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void*
                                       *reinterpret_cast<EpiPlain<float>*>(&ep), *reinterpret_cast<EpiQkv<float>*>(&eq), st);
   VY_CHECK_LAUNCH(who);
   if (cos_tab && !fuse) {
+    if (pos_dev) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: device-side position needs the fused RoPE path (bf16, dh == 64)", who);
     const int vdt = sizeof(T) == 2 ? VY_BF16 : VY_F32;
     if (int rc = vy_rope_fwd(q, q_sb, q_sh, q_sl, cos_tab, sin_tab, pos0, B, h, L, dh, 0, vdt, st)) return rc;
     if (int rc = vy_rope_fwd(k, k_sb, k_sh, k_sl, cos_tab, sin_tab, pos0, B, hk, L, dh, 0, vdt, st)) return rc;
@@ -930,5 +1031,19 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
     return qkv_impl<bf16>(x, ldx, w, ldw, bias, cos_tab, sin_tab, pos0, q, q_sb, q_sh, q_sl, k, k_sb, k_sh, k_sl, v, v_sb, v_sh, v_sl, B, L, K, h, hk, dh, st);
   if (dtype == VY_F32)
     return qkv_impl<float>(x, ldx, w, ldw, bias, cos_tab, sin_tab, pos0, q, q_sb, q_sh, q_sl, k, k_sb, k_sh, k_sl, v, v_sb, v_sh, v_sl, B, L, K, h, hk, dh, st);
+  VY_FAIL(VY_ERR_ARG, "vy_qkv_rope_fwd: bad dtype %d", dtype);
+}
+
+// internal: vy_qkv_rope_fwd with the token position read from device memory (graph replay)
+int vy_qkv_rope_fwd_ex(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                       const float* cos_tab, const float* sin_tab, int64_t pos0, const int* pos_dev, void* q,
+                       int64_t q_sb, int64_t q_sh, int64_t q_sl, void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                       void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t L, int64_t K, int h,
+                       int hk, int dh, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_BF16)
+    return qkv_impl<bf16>(x, ldx, w, ldw, bias, cos_tab, sin_tab, pos0, q, q_sb, q_sh, q_sl, k, k_sb, k_sh, k_sl, v, v_sb, v_sh, v_sl, B, L, K, h, hk, dh, st, pos_dev);
+  if (dtype == VY_F32)
+    return qkv_impl<float>(x, ldx, w, ldw, bias, cos_tab, sin_tab, pos0, q, q_sb, q_sh, q_sl, k, k_sb, k_sh, k_sl, v, v_sb, v_sh, v_sl, B, L, K, h, hk, dh, st, pos_dev);
   VY_FAIL(VY_ERR_ARG, "vy_qkv_rope_fwd: bad dtype %d", dtype);
 }

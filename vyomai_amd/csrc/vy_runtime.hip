@@ -1,0 +1,90 @@
+// Native decode driver (host code): chains the kernel launchers for one single-token step so the
+// Python side makes ONE call per generated token.  See include/vyom_hip.h (vy_decoder_step).
+#include "vy_common.h"
+
+int vy_qkv_rope_fwd_ex(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                       const float* cos_tab, const float* sin_tab, int64_t pos0, const int* pos_dev, void* q,
+                       int64_t q_sb, int64_t q_sh, int64_t q_sl, void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,
+                       void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t L, int64_t K, int h,
+                       int hk, int dh, int dtype, void* stream);
+int vy_attn_decode_ex(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb, int64_t k_sh,
+                      int64_t k_sl, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl, void* out,
+                      int64_t o_sb, int64_t B, int h, int hk, int64_t S, const int* pos_dev, int dh, float scale,
+                      int dtype, void* stream);
+
+namespace {
+inline int64_t esize(int dtype) { return dtype == VY_BF16 ? 2 : 4; }
+inline int64_t up(int64_t x) { return (x + 255) / 256 * 256; }
+}  // namespace
+
+extern "C" int64_t vy_decode_ws_bytes(int32_t B, int32_t d, int32_t h, int32_t hk, int32_t dh, int32_t ffn,
+                                      int32_t dtype) {
+  const int64_t e = esize(dtype);
+  // q, attn out, s (pre-LN), a (post-LN1), mid (ffn), two ping-pong hidden buffers
+  return up(B * (int64_t)h * dh * e) + 5 * up(B * (int64_t)d * e) + up(B * (int64_t)ffn * e) + 4096;
+}
+
+extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t pos, const int32_t* pos_dev,
+                               void* hidden_out, void* logits, int64_t ldv, void* stream) {
+  const char* who = "vy_decoder_step";
+  if (!p || !x || !p->layers || !p->ws) VY_FAIL(VY_ERR_ARG, "%s: null plan/input/workspace", who);
+  if (p->ws_bytes < vy_decode_ws_bytes(p->B, p->d, p->h, p->hk, p->dh, p->ffn, p->dtype))
+    VY_FAIL(VY_ERR_ARG, "%s: workspace too small", who);
+  const int64_t e = esize(p->dtype);
+  const int B = p->B, d = p->d, h = p->h, hk = p->hk, dh = p->dh;
+  char* w = (char*)p->ws;
+  void* q = w; w += up(B * (int64_t)h * dh * e);
+  void* ao = w; w += up(B * (int64_t)d * e);
+  void* s = w; w += up(B * (int64_t)d * e);
+  void* a = w; w += up(B * (int64_t)d * e);
+  void* hb[2];
+  hb[0] = w; w += up(B * (int64_t)d * e);
+  hb[1] = w; w += up(B * (int64_t)d * e);
+  void* mid = w;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const void* cur = x;
+  for (int l = 0; l < p->num_layers; ++l) {
+    const vy_decode_layer& L = p->layers[l];
+    if (!pos_dev && pos < 0) VY_FAIL(VY_ERR_ARG, "%s: negative position", who);
+    // K/V of this token go straight into the cache at index pos (host offset, or the kernel adds
+    // *pos_dev itself when the step is being captured into a graph)
+    const int64_t hpos = pos_dev ? 0 : pos;
+    void* kdst = (char*)L.kcache + hpos * L.c_sl * e;
+    void* vdst = (char*)L.vcache + hpos * L.c_sl * e;
+    int rc = vy_qkv_rope_fwd_ex(cur, d, L.wqkv, d, L.bqkv, p->cos_tab, p->sin_tab, pos, pos_dev, q, (int64_t)h * dh,
+                                dh, dh, kdst, L.c_sb, L.c_sh, L.c_sl, vdst, L.c_sb, L.c_sh, L.c_sl, B, 1, d, h, hk,
+                                dh, p->dtype, stream);
+    if (rc) return rc;
+    rc = vy_attn_decode_ex(q, (int64_t)h * dh, dh, L.kcache, L.c_sb, L.c_sh, L.c_sl, L.vcache, L.c_sb, L.c_sh,
+                           L.c_sl, ao, d, B, h, hk, pos + 1, pos_dev, dh, scale, p->dtype, stream);
+    if (rc) return rc;
+    rc = vy_linear_fwd(ao, d, L.wo, d, L.bo, cur, d, s, d, nullptr, B, d, d, VY_ACT_NONE, p->dtype, stream);
+    if (rc) return rc;
+    rc = vy_layernorm_fwd(s, d, L.ln1_w, L.ln1_b, a, d, nullptr, nullptr, B, d, p->eps_attn, p->dtype, stream);
+    if (rc) return rc;
+    rc = vy_linear_fwd(a, d, L.w1, d, L.b1, nullptr, 0, mid, p->ffn, nullptr, B, p->ffn, d, p->act, p->dtype, stream);
+    if (rc) return rc;
+    // FFN residual = the LAYER INPUT (reference models/decoder.py:241-250)
+    rc = vy_linear_fwd(mid, p->ffn, L.w2, p->ffn, L.b2, cur, d, s, d, nullptr, B, d, p->ffn, VY_ACT_NONE, p->dtype, stream);
+    if (rc) return rc;
+    void* nxt = hb[l & 1];
+    rc = vy_layernorm_fwd(s, d, L.ln2_w, L.ln2_b, nxt, d, nullptr, nullptr, B, d, p->eps_ffn, p->dtype, stream);
+    if (rc) return rc;
+    cur = nxt;
+  }
+  if (hidden_out && hidden_out != cur) {
+    if (hipMemcpyAsync(hidden_out, cur, B * (int64_t)d * e, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+      VY_FAIL(VY_ERR_LAUNCH, "%s: copy of the hidden state failed", who);
+  }
+  if (logits) {
+    int rc = vy_linear_fwd(cur, d, p->head_wd, d, p->head_bd, nullptr, 0, s, d, nullptr, B, d, d, VY_ACT_GELU_ERF,
+                           p->dtype, stream);
+    if (rc) return rc;
+    rc = vy_layernorm_fwd(s, d, p->head_ln_w, p->head_ln_b, a, d, nullptr, nullptr, B, d, p->eps_head, p->dtype, stream);
+    if (rc) return rc;
+    rc = vy_linear_fwd(a, d, p->head_wv, d, p->head_bias, nullptr, 0, logits, ldv, nullptr, B, p->vocab, d,
+                       VY_ACT_NONE, p->dtype, stream);
+    if (rc) return rc;
+  }
+  return VY_OK;
+}

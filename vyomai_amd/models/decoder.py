@@ -160,15 +160,26 @@ class DecoderModel(nn.Module, PositionMixin):
                                           dtype=self.compute_dtype or self.word_embeddings.weight.dtype)
             else:
                 kv_cache = DynamicCacheOne(self.config)
+        plan = None  # native single-token driver (one C call per step) once the prompt is cached
         prev_pos = 0
         eos_reached = torch.zeros(bsz, dtype=torch.bool, device=device)
         input_text_mask = tokens != pad_id
         stop_tokens = torch.tensor(getattr(self.config, "eos_token_id", 2), device=device)
         for cur_pos in range(prompt_len, total):
-            outputs = self.forward(input_ids=tokens[:, prev_pos:cur_pos], attention_mask=attention_mask,
-                                   use_cache=use_cache, kv_cache=kv_cache, start_pos=prev_pos)
-            kv_cache = outputs.kv_cache
-            next_token_logits = outputs.logits[:, -1] / temperature
+            if use_cache and use_static_cache and cur_pos - prev_pos == 1 and device.type == "cuda":
+                if plan is None:
+                    from ..decode_plan import DecodePlan
+                    plan = DecodePlan(self, kv_cache, bsz, self.compute_dtype or self.word_embeddings.weight.dtype,
+                                      device)
+                hidden = self.word_embeddings(tokens[:, prev_pos:cur_pos])
+                hidden, _ = self._positions(hidden, prev_pos, 1)
+                logits, _ = plan.step(hidden[:, 0, :].contiguous(), prev_pos)
+                next_token_logits = logits / temperature
+            else:
+                outputs = self.forward(input_ids=tokens[:, prev_pos:cur_pos], attention_mask=attention_mask,
+                                       use_cache=use_cache, kv_cache=kv_cache, start_pos=prev_pos)
+                kv_cache = outputs.kv_cache
+                next_token_logits = outputs.logits[:, -1] / temperature
             if do_sample:
                 # the reference samples from the raw logits (:491-492); kept
                 next_token = torch.multinomial(next_token_logits.float(), num_samples=1)
