@@ -123,6 +123,17 @@ int vy_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, const void* 
                      int64_t ldy, float* mean, float* rstd, int64_t M, int64_t N, float eps,
                      int dtype, void* stream);
 
+/* vy_rmsnorm_fwd: y = x * rsqrt(mean(x^2) + eps) * (w_offset + w); Gemma uses w_offset = 1
+ * (Examples/paligemma.ipynb cell 11, GemmaRMSNorm).  Statistics in fp32. */
+int vy_rmsnorm_fwd(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M,
+                   int64_t N, float eps, float w_offset, int dtype, void* stream);
+
+/* vy_gated_act_fwd: out[m, i] = act(gate_up[m, i]) * gate_up[m, I + i] -- the GeGLU of GemmaMLP
+ * (Examples/paligemma.ipynb cell 11: gelu_tanh(gate_proj(x)) * up_proj(x)) after one packed
+ * [gate; up] projection. */
+int vy_gated_act_fwd(const void* gate_up, int64_t ldg, void* out, int64_t ldo, int64_t M, int64_t I,
+                     int act, int dtype, void* stream);
+
 /* vy_rope_fwd: in-place rotary embedding on a (B,heads,L,dh) tensor (strides as above);
  * used when the fused epilogue does not apply.  `inverse` != 0 applies the transpose rotation
  * (the backward of RoPE).  replaces: VyomAI/layers/positional_embeddings.py:155-182. */
@@ -159,7 +170,9 @@ int vy_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
 
 /* Flash attention backward.  dO/O are (B,L,h*dh) (strides {sb,sl}); dq/dk/dv use q/k/v layouts.
  * delta_ws: fp32 [B,h,L] scratch.  dk/dv are (B,hk,S,dh): the n_rep query heads of one kv head
- * are summed in-kernel.  Same mask descriptor as the forward. */
+ * are summed in-kernel.  Same mask descriptor as the forward.  cos_tab/sin_tab (nullable): when
+ * q/k were rotated by RoPE (row rope_pos0 + token of the tables), the inverse rotation is applied
+ * to dq and dk in the epilogues, so they are gradients w.r.t. the un-rotated projections. */
 int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl,
                 const void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                 const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl,
@@ -169,6 +182,7 @@ int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl,
                 void* dk, int64_t dk_sb, int64_t dk_sh, int64_t dk_sl,
                 void* dv, int64_t dv_sb, int64_t dv_sh, int64_t dv_sl,
                 int mask_kind, int64_t start_pos, const uint8_t* keypad, int64_t kp_sb,
+                const float* cos_tab, const float* sin_tab, int64_t rope_pos0,
                 int64_t B, int h, int hk, int64_t L, int64_t S, int dh, float scale, int dtype,
                 void* stream);
 

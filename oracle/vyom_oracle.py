@@ -494,14 +494,51 @@ def generate(sd: SD, cfg: Cfg, ids: Tensor, max_new_tokens: int, pos_type="absol
 
 
 # ----------------------------------------------------------------------------
-# PaliGemma-shape blocks (Examples/paligemma.ipynb cells 9, 11-13) -- parity unpinned
-# w.r.t. reference-generated vectors: the notebook has no importable module.
+# PaliGemma-shape blocks (Examples/paligemma.ipynb cells 9, 11-13).  The notebook has no importable
+# module; its class-definition cells are exec'd by tests/golden/make_golden.py to pin the layer
+# blocks (tests/golden/paligemma_blocks.npz).  The cached decode loop around them is unpinned.
 # ----------------------------------------------------------------------------
 
 
 def gemma_mlp(x: Tensor, w_gate: Tensor, w_up: Tensor, w_down: Tensor) -> Tensor:
     """down(gelu_tanh(gate(x)) * up(x)), no biases (cell 13)."""
     return linear(gelu_tanh(linear(x, w_gate)) * linear(x, w_up), w_down)
+
+
+def siglip_layer(sd: SD, p: str, x: Tensor, heads: int, eps: float) -> Tensor:
+    """SiglipEncoderLayer: pre-LN, h + out_proj(attn(LN1 h)); h + fc2(gelu_tanh(fc1(LN2 h))).
+    Softmax in fp32, no mask.  Examples/paligemma.ipynb cell 9."""
+    d = x.shape[-1]
+    dh = d // heads
+    n = layer_norm(x, sd[p + "layer_norm1.weight"], sd[p + "layer_norm1.bias"], eps)
+    q = split_heads(linear(n, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]), dh)
+    k = split_heads(linear(n, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"]), dh)
+    v = split_heads(linear(n, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"]), dh)
+    a = merge_heads(sdpa(q, k, v, None))
+    x = x + linear(a, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
+    n = layer_norm(x, sd[p + "layer_norm2.weight"], sd[p + "layer_norm2.bias"], eps)
+    m = gelu_tanh(linear(n, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    return x + linear(m, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+def gemma_layer(sd: SD, p: str, x: Tensor, heads: int, kv_heads: int, head_dim: int, eps: float,
+                mask: Optional[Tensor], pos0: int = 0, cache=None, layer_idx: int = 0) -> Tensor:
+    """GemmaDecoderLayer: pre-RMSNorm, RoPE (NeoX halves, theta 10000), MQA/GQA by repeat_kv, softmax in
+    fp32, GeGLU MLP, no biases.  Examples/paligemma.ipynb cells 11-13."""
+    L = x.shape[1]
+    n = rms_norm_gemma(x, sd[p + "input_layernorm.weight"], eps)
+    q = split_heads(linear(n, sd[p + "self_attn.q_proj.weight"]), head_dim)
+    k = split_heads(linear(n, sd[p + "self_attn.k_proj.weight"]), head_dim)
+    v = split_heads(linear(n, sd[p + "self_attn.v_proj.weight"]), head_dim)
+    freqs = rotary_angles(head_dim, pos0 + L)[:, pos0:pos0 + L]
+    q, k = apply_rotary(q, k, freqs)
+    if cache is not None:
+        k, v = cache.update(layer_idx, k, v, pos0)
+    k, v = repeat_kv(k, heads // kv_heads), repeat_kv(v, heads // kv_heads)
+    a = merge_heads(sdpa(q, k, v, mask))
+    x = x + linear(a, sd[p + "self_attn.o_proj.weight"])
+    n = rms_norm_gemma(x, sd[p + "post_attention_layernorm.weight"], eps)
+    return x + gemma_mlp(n, sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"])
 
 
 def clm_loss(logits: Tensor, labels: Tensor) -> Tensor:

@@ -201,3 +201,33 @@ def vit_shapes(cfg, p=""):
     s[p + "pixel_seq.weight"] = (d, cfg.num_channels, ph, pw)
     s[p + "pixel_seq.bias"] = (d,)
     return s
+
+
+# PaliGemma shapes (module dump in Examples/paligemma.ipynb cell 24 output)
+SIGLIP = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16,
+              num_channels=3, image_size=224, patch_size=14, layer_norm_eps=1e-6, attention_dropout=0.0)
+GEMMA = dict(hidden_size=2048, intermediate_size=16384, num_hidden_layers=18, num_attention_heads=8,
+             head_dim=256, num_key_value_heads=1, rms_norm_eps=1e-6, attention_bias=False,
+             attention_dropout=0.0, max_position_embeddings=8192, rope_theta=10000.0, vocab_size=257216,
+             pad_token_id=0)
+
+
+def siglip_layer_shapes(p=""):
+    d, i = SIGLIP["hidden_size"], SIGLIP["intermediate_size"]
+    s = {}
+    for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+        s[f"{p}self_attn.{n}.weight"], s[f"{p}self_attn.{n}.bias"] = (d, d), (d,)
+    for n in ("layer_norm1", "layer_norm2"):
+        s[f"{p}{n}.weight"], s[f"{p}{n}.bias"] = (d,), (d,)
+    s[f"{p}mlp.fc1.weight"], s[f"{p}mlp.fc1.bias"] = (i, d), (i,)
+    s[f"{p}mlp.fc2.weight"], s[f"{p}mlp.fc2.bias"] = (d, i), (d,)
+    return s
+
+
+def gemma_layer_shapes(p=""):
+    d, i = GEMMA["hidden_size"], GEMMA["intermediate_size"]
+    h, hk, dh = GEMMA["num_attention_heads"], GEMMA["num_key_value_heads"], GEMMA["head_dim"]
+    return {f"{p}self_attn.q_proj.weight": (h * dh, d), f"{p}self_attn.k_proj.weight": (hk * dh, d),
+            f"{p}self_attn.v_proj.weight": (hk * dh, d), f"{p}self_attn.o_proj.weight": (d, h * dh),
+            f"{p}mlp.gate_proj.weight": (i, d), f"{p}mlp.up_proj.weight": (i, d), f"{p}mlp.down_proj.weight": (d, i),
+            f"{p}input_layernorm.weight": (d,), f"{p}post_attention_layernorm.weight": (d,)}

@@ -236,7 +236,52 @@ def gradients():
     save("grads", **out)
 
 
+# ---------------------------------------------------------------------------
+# E. PaliGemma-shape blocks: the reference ships them only as notebook cells
+#    (Examples/paligemma.ipynb cells 9, 11-13).  The class-definition cells are exec'd here
+#    (plain torch + einops code) and run at the true widths on a few tokens.
+# ---------------------------------------------------------------------------
+
+
+def paligemma_blocks():
+    import json
+    import logging
+    import math
+    import types
+    from einops import rearrange
+    nb = json.load(open("/root/reference/Examples/paligemma.ipynb"))
+    ns = {"rearrange": rearrange, "math": math, "Cache": object, "GemmaConfig": object,
+          "logger": logging.getLogger("pg"), "Optional": Optional, "Tuple": Tuple, "dataclass": dataclass,
+          "torch": torch, "nn": torch.nn}
+    import typing
+    ns.update({k: getattr(typing, k) for k in ("List", "Union", "Dict", "Any")})
+    for i in (9, 11, 12, 13):
+        exec("".join(nb["cells"][i]["source"]), ns)
+    out = {}
+    scfg = ns["SiglipVisionConfig"](**cases.SIGLIP)
+    layer = filled(ns["SiglipEncoderLayer"](scfg), "pg.siglip.")
+    x = T(recipe.uniform("pg.siglip.x", (2, 20, scfg.hidden_size)))
+    out["siglip.layer"] = layer(x)
+    gcfg = types.SimpleNamespace(**cases.GEMMA)
+    glayer = filled(ns["GemmaDecoderLayer"](gcfg, 0), "pg.gemma.")
+    xg = T(recipe.uniform("pg.gemma.x", (2, 12, gcfg.hidden_size)))
+    pos = torch.arange(12)[None, :].expand(2, -1)
+    out["gemma.layer.nomask"] = glayer(xg, attention_mask=None, position_ids=pos)[0]
+    causal = T(cases.causal_additive(2, 12, 0, None))
+    out["gemma.layer.causal"] = glayer(xg, attention_mask=causal, position_ids=pos)[0]
+    out["gemma.layer.pos7"] = glayer(xg, attention_mask=causal, position_ids=pos + 7)[0]
+    norm = filled(ns["GemmaRMSNorm"](gcfg.hidden_size, eps=gcfg.rms_norm_eps), "pg.norm.")
+    out["gemma.rmsnorm"] = norm(xg)
+    save("paligemma_blocks", **{k: cases.sub2(v.reshape(-1, v.shape[-1])) if v.numel() > 20000 else v for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    module_level()
-    model_level()
-    gradients()
+    which = sys.argv[1:] or ["modules", "models", "grads", "paligemma"]
+    if "modules" in which:
+        module_level()
+    if "models" in which:
+        model_level()
+    if "grads" in which:
+        gradients()
+    if "paligemma" in which:
+        paligemma_blocks()

@@ -135,3 +135,30 @@ def test_adamw_matches_torch():
         ops.adamw_step(p, (g * step).to(DEV), m, v, pb, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
     check(p, pt.detach(), 1e-6, 1e-5, "adamw")
     check(pb, pt.detach().to(BF), 1e-2, 1e-2, "adamw bf16 shadow")
+
+
+def test_attention_bwd_fused_rope_inverse():
+    """dq/dk with the RoPE backward fused into the epilogues == separate inverse rotation."""
+    ops = _ops()
+    B, h, hk, L, dh = 2, 4, 2, 96, 64
+    q, k, v = rnd(B, h, L, dh, seed=1).to(BF), rnd(B, hk, L, dh, seed=2).to(BF), rnd(B, hk, L, dh, seed=3).to(BF)
+    do = rnd(B, L, h * dh, seed=4).to(BF)
+    cos, sin = ops.rope_tables(dh, 128, DEV)
+    qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
+    lse = torch.zeros(B, h, L, dtype=torch.float32, device=DEV)
+    out = ops.attention(qg, kg, vg, causal=True, lse=lse)
+    def run(fused):
+        dq = torch.zeros(B, h, L, dh, dtype=BF, device=DEV)
+        dk = torch.zeros(B, hk, L, dh, dtype=BF, device=DEV)
+        dv = torch.zeros_like(dk)
+        if fused:
+            ops.attention_bwd(qg, kg, vg, out, do.to(DEV), lse, dq, dk, dv, causal=True, cos=cos, sin=sin, rope_pos0=3)
+        else:
+            ops.attention_bwd(qg, kg, vg, out, do.to(DEV), lse, dq, dk, dv, causal=True)
+            ops.rope_(dq, cos, sin, 3, inverse=True)
+            ops.rope_(dk, cos, sin, 3, inverse=True)
+        return dq, dk, dv
+    a, b = run(True), run(False)
+    check(a[0], b[0], 2e-2, 2e-2, "dq")
+    check(a[1], b[1], 2e-2, 2e-2, "dk")
+    check(a[2], b[2], 0, 0, "dv")

@@ -207,3 +207,26 @@ def test_gradients(golden, tag, at):
         got = p.grad if p.grad.numel() <= 4096 else cases.sub2(p.grad)
         scale = max(1.0, float(np.abs(want).max()))
         close(got, want, 2e-5 * scale, what=n)
+
+
+def test_paligemma_blocks(golden):
+    """SigLIP and Gemma layers (true widths) vs the exec'd notebook cells."""
+    g = golden("paligemma_blocks")
+    S, G = cases.SIGLIP, cases.GEMMA
+    sd = sd_from(cases.siglip_layer_shapes(), "pg.siglip.")
+    x = T(recipe.uniform("pg.siglip.x", (2, 20, S["hidden_size"])))
+    y = O.siglip_layer(sd, "", x, S["num_attention_heads"], S["layer_norm_eps"])
+    close(cases.sub2(y.reshape(-1, y.shape[-1])), g["siglip.layer"], 1e-5, "siglip layer")
+    sd = sd_from(cases.gemma_layer_shapes(), "pg.gemma.")
+    xg = T(recipe.uniform("pg.gemma.x", (2, 12, G["hidden_size"])))
+    args = (G["num_attention_heads"], G["num_key_value_heads"], G["head_dim"], G["rms_norm_eps"])
+    causal = T(cases.causal_additive(2, 12, 0, None))
+    for key, mask, pos0 in (("nomask", None, 0), ("causal", causal, 0), ("pos7", causal, 7)):
+        y = O.gemma_layer(sd, "", xg, *args, mask, pos0)
+        want = g[f"gemma.layer.{key}"]
+        got = cases.sub2(y.reshape(-1, y.shape[-1]))
+        scale = max(1.0, float(np.abs(want).max()))
+        close(got, want, 2e-5 * scale, f"gemma layer {key}")
+    w = T(recipe.param_value("pg.norm.weight", (G["hidden_size"],)))
+    y = O.rms_norm_gemma(xg, w, G["rms_norm_eps"])
+    close(cases.sub2(y.reshape(-1, y.shape[-1])), g["gemma.rmsnorm"], 2e-6, "rmsnorm")

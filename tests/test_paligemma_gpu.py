@@ -1,0 +1,120 @@
+"""PaliGemma-shape path (BASELINE.json configs[4]) on the MI355X.
+
+The layer blocks are pinned to the reference notebook's own classes (exec'd cells,
+tests/golden/paligemma_blocks.npz); the cached decode loop around them has no importable
+reference ("parity unpinned" for that part) and is checked against the oracle's restatement."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vyom_oracle as O
+from tests.golden import cases
+from vyomai_amd import recipe
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def fill(mod, prefix):
+    for n, t in mod.state_dict().items():
+        if t.is_floating_point():
+            t.copy_(T(recipe.param_value(prefix + n, tuple(t.shape))))
+    return mod.to(DEV).eval()
+
+
+def close(got, want, atol, what):
+    got = got.detach().float().cpu().numpy()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = np.abs(got - want).max()
+    assert np.isfinite(got).all() and err <= atol, f"{what}: max abs err {err:.3e} > {atol}"
+
+
+def test_blocks_fp32_vs_notebook():
+    from vyomai_amd.models import paligemma as P
+    from vyomai_amd.layers.positional_embeddings import RopeTable
+    g = dict(np.load("tests/golden/paligemma_blocks.npz"))
+    scfg = P.SiglipVisionConfig(**cases.SIGLIP)
+    layer = fill(P.SiglipEncoderLayer(scfg), "pg.siglip.")
+    x = T(recipe.uniform("pg.siglip.x", (2, 20, scfg.hidden_size))).to(DEV)
+    with torch.no_grad():
+        y = layer(x)
+    close(cases.sub2(y.reshape(-1, y.shape[-1])), g["siglip.layer"], 2e-5, "siglip layer (dh=72)")
+    gcfg = types.SimpleNamespace(**cases.GEMMA)
+    glayer = fill(P.GemmaDecoderLayer(gcfg, 0), "pg.gemma.")
+    xg = T(recipe.uniform("pg.gemma.x", (2, 12, gcfg.hidden_size))).to(DEV)
+    rope = RopeTable(P._angles(gcfg.head_dim, 64, gcfg.rope_theta))
+    with torch.no_grad():
+        for key, causal, pos0 in (("nomask", False, 0), ("causal", True, 0)):
+            y = glayer(xg, rope, pos0, causal=causal)
+            want = g[f"gemma.layer.{key}"]
+            close(cases.sub2(y.reshape(-1, y.shape[-1])), want, 3e-5 * max(1.0, float(np.abs(want).max())),
+                  f"gemma layer {key} (MQA, dh=256)")
+        norm = fill(P.GemmaRMSNorm(gcfg.hidden_size, gcfg.rms_norm_eps), "pg.norm.")
+        y = norm(xg)
+        close(cases.sub2(y.reshape(-1, y.shape[-1])), g["gemma.rmsnorm"], 2e-6, "rmsnorm")
+
+
+def test_gemma_cached_decode_matches_full_recompute():
+    """KV-cache decode of the Gemma block stack == recomputing the whole sequence (fp32, token-exact
+    hidden states to 1e-5), at reduced depth; MQA with head_dim 256."""
+    from vyomai_amd.models import paligemma as P
+    from vyomai_amd.layers.positional_embeddings import RopeTable
+    small = dict(cases.GEMMA, num_hidden_layers=2, intermediate_size=1024, vocab_size=512)
+    gcfg = types.SimpleNamespace(**small)
+    layers = [fill(P.GemmaDecoderLayer(gcfg, i), f"pgs.{i}.") for i in range(2)]
+    rope = RopeTable(P._angles(gcfg.head_dim, 64, gcfg.rope_theta))
+    B, Lp, steps = 2, 9, 4
+    xs = T(recipe.uniform("pgs.x", (B, Lp + steps, gcfg.hidden_size))).to(DEV)
+    caches = [(torch.zeros(B, 1, 32, gcfg.head_dim, device=DEV), torch.zeros(B, 1, 32, gcfg.head_dim, device=DEV))
+              for _ in layers]
+    with torch.no_grad():
+        h = xs[:, :Lp]
+        for l, c in zip(layers, caches):
+            h = l(h, rope, 0, causal=True, cache=c)
+        outs = [h[:, -1:]]
+        for s in range(steps):
+            h = xs[:, Lp + s:Lp + s + 1]
+            for l, c in zip(layers, caches):
+                h = l(h, rope, Lp + s, cache=c)
+            outs.append(h)
+        full = xs
+        for l in layers:
+            full = l(full, rope, 0, causal=True)
+    got = torch.cat(outs, dim=1)
+    want = full[:, Lp - 1:]
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    # and against the CPU oracle restatement of the same blocks
+    sd = {}
+    for i in range(2):
+        shapes = {k: v for k, v in cases.gemma_layer_shapes(f"L{i}.").items()}
+        for n, shp in shapes.items():
+            shp = tuple(1024 if d_ == 16384 else d_ for d_ in shp)
+            sd[n] = T(recipe.param_value(f"pgs.{i}." + n[len(f"L{i}."):], shp))
+    ref = xs.cpu()
+    mask = T(cases.causal_additive(B, Lp + steps, 0, None))
+    for i in range(2):
+        ref = O.gemma_layer(sd, f"L{i}.", ref, 8, 1, 256, 1e-6, mask, 0)
+    assert (full.cpu() - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_paligemma_shape_generate_bf16_runs():
+    """Reduced-depth PaliGemma-shaped model end to end in bf16: image -> 256 tokens -> prefix -> greedy
+    decode; finite logits, right shapes, cache positions advance."""
+    from vyomai_amd.models import paligemma as P
+    vis = P.SiglipVisionConfig(**dict(cases.SIGLIP, num_hidden_layers=2))
+    txt = types.SimpleNamespace(**dict(cases.GEMMA, num_hidden_layers=2, vocab_size=4096))
+    m = P.PaliGemmaForConditionalGeneration(P.PaliGemmaShape(vis, txt, txt.hidden_size))
+    for n, p in m.named_parameters():
+        with torch.no_grad():
+            p.copy_(T(recipe.param_value("pgm." + n, tuple(p.shape))))
+    m = m.to(DEV).to(torch.bfloat16).eval()
+    img = T(recipe.uniform("pgm.img", (1, 3, 224, 224), 0.5, 0.5)).to(DEV)
+    ids = T(recipe.token_ids("pgm.ids", (1, 8), 3, 4096)).to(DEV)
+    out = m.generate(img, ids, max_new_tokens=6, max_cache_len=384)
+    assert out.shape == (1, 6) and int(out.min()) >= 0 and int(out.max()) < 4096

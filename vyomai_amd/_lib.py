@@ -30,6 +30,8 @@ PROTOTYPES = {
     "vy_attn_decode": [_p, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,
                        _p, _i64, _i64, _i, _i, _i64, _i, _f, _i, _p],
     "vy_layernorm_fwd": [_p, _i64, _p, _p, _p, _i64, _p, _p, _i64, _i64, _f, _i, _p],
+    "vy_rmsnorm_fwd": [_p, _i64, _p, _p, _i64, _i64, _i64, _f, _f, _i, _p],
+    "vy_gated_act_fwd": [_p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
     "vy_rope_fwd": [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i, _i64, _i, _i, _i, _p],
     "vy_linear_dgrad": [_p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i64, _i64, _i64, _i, _p],
     "vy_linear_wgrad": [_p, _i64, _p, _i64, _p, _i64, _p, _f, _i64, _i64, _i64, _i, _p],
@@ -37,7 +39,7 @@ PROTOTYPES = {
     "vy_attn_bwd": [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,
                     _p, _p, _i64, _i64, _p, _p,
                     _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,
-                    _i, _i64, _p, _i64, _i64, _i, _i, _i64, _i64, _i, _f, _i, _p],
+                    _i, _i64, _p, _i64, _p, _p, _i64, _i64, _i, _i, _i64, _i64, _i, _f, _i, _p],
     "vy_adamw_step": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p],
     "vy_act_bwd": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
     "vy_xent_fwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],

@@ -185,10 +185,9 @@ class SelfAttentionFn(torch.autograd.Function):
         dq = packed[:, :, : h * dh].view(B, L, h, dh).permute(0, 2, 1, 3)
         dk = packed[:, :, h * dh:(h + hk) * dh].view(B, L, hk, dh).permute(0, 2, 1, 3)
         dv = packed[:, :, (h + hk) * dh:].view(B, L, hk, dh).permute(0, 2, 1, 3)
-        ops.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, causal=causal, start_pos=sp, keypad=kp)
-        if cos is not None:  # RoPE is orthogonal: its backward is the inverse rotation
-            ops.rope_(dq, cos, sin, pos0, inverse=True)
-            ops.rope_(dk, cos, sin, pos0, inverse=True)
+        # RoPE is orthogonal: its backward (the inverse rotation of dq, dk) runs in the epilogues
+        ops.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, causal=causal, start_pos=sp, keypad=kp,
+                          cos=cos, sin=sin, rope_pos0=pos0)
         w, b = mod._packed()
         dx = ops.linear_dgrad(packed, _wt_packed(mod, w, dt))
         grads = _packed_wgrad(mod, packed, x, w, b, params)

@@ -298,8 +298,16 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnParams p, int dh)
   const T* Q = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qi * p.q_sl;
   const T* Kb = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
   const T* Vb = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+  // head dims whose chunk count is not a power of two (SigLIP: 72 = 9 chunks of 8) run with the
+  // next power of two lanes per key; the surplus lanes carry zeros and never store
+  const bool ch_ok = ch * VEC < dh;
+  const int chl = ch_ok ? ch : 0;  // a valid address for the idle lanes
   float qv[VEC];
-  RowVec<T>::load(Q + ch * VEC, qv);
+  RowVec<T>::load(Q + chl * VEC, qv);
+  if (!ch_ok) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) qv[e] = 0.f;
+  }
   const bool causal = p.mask_kind & VY_MASK_CAUSAL;
   const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
   const bool hasadd = p.mask_kind & VY_MASK_ADDITIVE;
@@ -325,10 +333,10 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnParams p, int dh)
       const int j = j0 + u * 4 * KPP + grp;
       valid[u] = j < S_eff;
       jc[u] = valid[u] ? j : S_eff - 1;
-      RowVec<T>::load(Kb + (int64_t)jc[u] * p.k_sl + ch * VEC, kv[u]);
+      RowVec<T>::load(Kb + (int64_t)jc[u] * p.k_sl + chl * VEC, kv[u]);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) RowVec<T>::load(Vb + (int64_t)jc[u] * p.v_sl + ch * VEC, vv[u]);
+    for (int u = 0; u < U; ++u) RowVec<T>::load(Vb + (int64_t)jc[u] * p.v_sl + chl * VEC, vv[u]);
     float mn = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnParams p, int dh)
     for (int e = 0; e < VEC; ++e) red_o[(wave * 64 + ch) * VEC + e] = acc[e];
   }
   __syncthreads();
-  if (wave == 0 && grp == 0) {
+  if (wave == 0 && grp == 0 && ch_ok) {
     float M_ = red_m[0];
     for (int w = 1; w < 4; ++w) M_ = fmaxf(M_, red_m[w * KPP]);
     float Ls = 0.f, out[VEC];
@@ -399,7 +407,8 @@ template <typename T>
 int launch_rowwise(const AttnParams& p, int dh, hipStream_t st, const char* who) {
   constexpr int VEC = RowVec<T>::VEC;
   if (dh % VEC) VY_FAIL(VY_ERR_ARG, "%s: head_dim %d not a multiple of %d", who, dh, VEC);
-  const int cpr = dh / VEC;
+  int cpr = 1;
+  while (cpr * VEC < dh) cpr <<= 1;  // lanes per key row, rounded up to a power of two
   const dim3 grid(p.L, p.h, p.B), block(256);
 #define RW_GO(C) hipLaunchKernelGGL((attn_rowwise_kernel<T, C>), grid, block, 0, st, p, dh)
   switch (cpr) {

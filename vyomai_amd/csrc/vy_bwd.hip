@@ -18,6 +18,7 @@
 // (dS = P o (dP - rowsum(dO o O))).
 #include "vy_common.h"
 #include <float.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -41,13 +42,17 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
 // wgrad: dW[n,k] += sum_m dY[m,n] X[m,k]
 // tile 128(n) x 128(k), 64 rows of m per stage, 4 waves 2x2 of 64x64, split over M
 // ------------------------------------------------------------------------------------------
-constexpr int WROW = 256;  // bytes per LDS row (128 bf16)
-
-__global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(
+// tile BN(n) x 128(k), 64 rows of m per stage; BN/64 x 2 waves of 64x64
+template <int BN>
+__global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
     float* __restrict__ dW, int64_t lddw, float* __restrict__ db, int M, int N, int K, int tiles_k,
     int tiles_nk, int m_chunk) {
-  constexpr int STAGE = 2 * 64 * WROW;  // dY tile + X tile
+  constexpr int NW = BN / 32;                 // waves: (BN/64) x 2
+  constexpr int AROW = BN * 2, BROW = 256;    // LDS row bytes of the dY and X tiles
+  constexpr int ATILE = 64 * AROW, BTILE = 64 * BROW;
+  constexpr int STAGE = ATILE + BTILE;
+  constexpr int PA = ATILE / 1024 / NW, PB = BTILE / 1024 / NW;  // LDS-DMA pieces per wave
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,34 +60,44 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int split = wg / tiles_nk, t2 = wg - split * tiles_nk;
   const int tile_n = t2 / tiles_k, tile_k = t2 - tile_n * tiles_k;
-  const int n0 = tile_n * 128, k0 = tile_k * 128;
+  const int n0 = tile_n * BN, k0 = tile_k * 128;
   const int m_begin = split * m_chunk;
   const int m_end = min(M, m_begin + m_chunk);
   if (m_begin >= m_end) return;
   const int nst = (m_end - m_begin + 63) / 64;
 
-  // LDS-DMA geometry: 16 pieces of 1 KiB (4 rows of 256 B) per tile, 4 per wave per operand
-  int ld_row[4], ld_off[4];
+  // LDS-DMA geometry: 1-KiB pieces; 64-byte swizzle (row & 3) << 6 on the source side
+  int a_row[PA], a_off[PA], b_row[PB], b_off[PB];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int P = (wave * 4 + t) * 1024 + lane * 16;
-    const int row = P / WROW, off = P % WROW;
-    ld_row[t] = row;
-    ld_off[t] = (off ^ ((row & 3) << 6)) >> 1;  // element offset, 64-B swizzle on the source side
+  for (int t = 0; t < PA; ++t) {
+    const int P = (wave * PA + t) * 1024 + lane * 16;
+    const int row = P / AROW, off = P % AROW;
+    a_row[t] = row;
+    a_off[t] = (off ^ ((row & 3) << 6)) >> 1;
+  }
+#pragma unroll
+  for (int t = 0; t < PB; ++t) {
+    const int P = (wave * PB + t) * 1024 + lane * 16;
+    const int row = P / BROW, off = P % BROW;
+    b_row[t] = row;
+    b_off[t] = (off ^ ((row & 3) << 6)) >> 1;
   }
   const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
   auto stage = [&](int s, int buf) {
     const int mb = m_begin + s * 64;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int m = mb + ld_row[t];
-      const bool mv = m < m_end;
-      const bf16* a = (mv && n0 + ld_off[t] < N) ? dY + (int64_t)m * lddy + n0 + ld_off[t] : zero;
-      const bf16* b = (mv && k0 + ld_off[t] < K) ? X + (int64_t)m * ldx + k0 + ld_off[t] : zero;
+    for (int t = 0; t < PA; ++t) {
+      const int m = mb + a_row[t];
+      const bf16* a = (m < m_end && n0 + a_off[t] < N) ? dY + (int64_t)m * lddy + n0 + a_off[t] : zero;
       __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)a,
-                                       (VY_LDS void*)(smem + buf * STAGE + (wave * 4 + t) * 1024), 16, 0, 0);
+                                       (VY_LDS void*)(smem + buf * STAGE + (wave * PA + t) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < PB; ++t) {
+      const int m = mb + b_row[t];
+      const bf16* b = (m < m_end && k0 + b_off[t] < K) ? X + (int64_t)m * ldx + k0 + b_off[t] : zero;
       __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)b,
-                                       (VY_LDS void*)(smem + buf * STAGE + 64 * WROW + (wave * 4 + t) * 1024), 16, 0, 0);
+                                       (VY_LDS void*)(smem + buf * STAGE + ATILE + (wave * PB + t) * 1024), 16, 0, 0);
     }
   };
 
@@ -109,8 +124,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(
   const int li = lane & 15, g16 = (lane >> 4) & 1, fh = lane >> 5;
   const int tr_row = 4 * fh + (li >> 2);                  // + 16*s (second read +8)
   const int tr_sw = ((li >> 2) & 3) << 6;                 // (row & 3) << 6
-  const int a_off = (2 * (wn * 64 + 16 * g16 + 4 * (li & 3)));  // + 64*i, then ^ tr_sw
-  const int b_off = (2 * (wk * 64 + 16 * g16 + 4 * (li & 3)));
+  const int a_rd = (2 * (wn * 64 + 16 * g16 + 4 * (li & 3)));  // + 64*i, then ^ tr_sw
+  const int b_rd = (2 * (wk * 64 + 16 * g16 + 4 * (li & 3)));
 
   stage(0, 0);
   __builtin_amdgcn_s_waitcnt(0);
@@ -119,16 +134,16 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_kernel(
     const int cur = s & 1;
     if (s + 1 < nst) stage(s + 1, cur ^ 1);
     const char* ab = smem + cur * STAGE;
-    const char* bb = ab + 64 * WROW;
+    const char* bb = ab + ATILE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 af[2], bfr[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        af[i] = tr_pair(ab + (16 * ks + tr_row) * WROW + ((a_off + 64 * i) ^ tr_sw), WROW);
+        af[i] = tr_pair(ab + (16 * ks + tr_row) * AROW + ((a_rd + 64 * i) ^ tr_sw), AROW);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        bfr[j] = tr_pair(bb + (16 * ks + tr_row) * WROW + ((b_off + 64 * j) ^ tr_sw), WROW);
+        bfr[j] = tr_pair(bb + (16 * ks + tr_row) * BROW + ((b_rd + 64 * j) ^ tr_sw), BROW);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -200,6 +215,7 @@ struct BwdParams {
   const uint8_t* keypad; int64_t kp_sb;
   int B, h, hk, L, S;
   float scale;
+  const float* cos_tab; const float* sin_tab; int rope_pos0;  // NULL: no RoPE backward fused
 };
 
 // delta[b,h,q] = sum_d dO[b,q,h*dh+d] * O[b,q,h*dh+d]; one wave per (b,q) row, dh = 64
@@ -221,6 +237,21 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(BwdParams p) {
     }
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
     if (c < nch && (c & 7) == 0) p.delta[((int64_t)b * p.h + (c >> 3)) * p.L + qi] = s;
+  }
+}
+
+// RoPE is an orthogonal map, so its backward is the transposed rotation of the gradient pair
+// (d, d+32): lo' = lo*c + hi*s, hi' = hi*c - lo*s, with the same storage-rounded cos/sin the forward
+// used.  pos = token position, d0 = first of the 4 consecutive d (< 32) of this quad.
+__device__ __forceinline__ void rope_bwd_quad(const BwdParams& p, int64_t pos, int d0, float (&lo)[4], float (&hi)[4]) {
+  const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.cos_tab + pos * 32 + d0);
+  const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.sin_tab + pos * 32 + d0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float c = vy_round_bf16(c4[e]), s = vy_round_bf16(s4[e]);
+    const float a = lo[e], b = hi[e];
+    lo[e] = a * c + b * s;
+    hi[e] = b * c - a * s;
   }
 }
 
@@ -358,14 +389,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
   if (qi < p.L) {
     bf16* D = p.dq + (int64_t)b * p.dq_sb + (int64_t)head * p.dq_sh + (int64_t)qi * p.dq_sl;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int rg = 0; rg < 4; ++rg) {
+      float lo[4], hi[4];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        bf16x4 w;
+      for (int e = 0; e < 4; ++e) { lo[e] = dq[0][4 * rg + e] * p.scale; hi[e] = dq[1][4 * rg + e] * p.scale; }
+      if (p.cos_tab) rope_bwd_quad(p, (int64_t)p.rope_pos0 + qi, 8 * rg + 4 * fh, lo, hi);
+      bf16x4 wl, wh;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = (bf16)(dq[n][4 * rg + e] * p.scale);
-        *reinterpret_cast<bf16x4*>(D + 32 * n + 8 * rg + 4 * fh) = w;
-      }
+      for (int e = 0; e < 4; ++e) { wl[e] = (bf16)lo[e]; wh[e] = (bf16)hi[e]; }
+      *reinterpret_cast<bf16x4*>(D + 8 * rg + 4 * fh) = wl;
+      *reinterpret_cast<bf16x4*>(D + 32 + 8 * rg + 4 * fh) = wh;
+    }
   }
 }
 
@@ -500,15 +534,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(BwdParams p) {
     bf16* DK = p.dk + (int64_t)b * p.dk_sb + (int64_t)kvh * p.dk_sh + (int64_t)kj * p.dk_sl;
     bf16* DV = p.dv + (int64_t)b * p.dv_sb + (int64_t)kvh * p.dv_sh + (int64_t)kj * p.dv_sl;
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int rg = 0; rg < 4; ++rg) {
+      float lo[4], hi[4];
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        bf16x4 a, w;
+      for (int e = 0; e < 4; ++e) { lo[e] = dk[0][4 * rg + e] * p.scale; hi[e] = dk[1][4 * rg + e] * p.scale; }
+      if (p.cos_tab) rope_bwd_quad(p, (int64_t)p.rope_pos0 + kj, 8 * rg + 4 * fh, lo, hi);
+      bf16x4 wl, wh, vl, vh;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = (bf16)(dk[n][4 * rg + e] * p.scale); w[e] = (bf16)dv[n][4 * rg + e]; }
-        *reinterpret_cast<bf16x4*>(DK + 32 * n + 8 * rg + 4 * fh) = a;
-        *reinterpret_cast<bf16x4*>(DV + 32 * n + 8 * rg + 4 * fh) = w;
+      for (int e = 0; e < 4; ++e) {
+        wl[e] = (bf16)lo[e]; wh[e] = (bf16)hi[e];
+        vl[e] = (bf16)dv[0][4 * rg + e]; vh[e] = (bf16)dv[1][4 * rg + e];
       }
+      *reinterpret_cast<bf16x4*>(DK + 8 * rg + 4 * fh) = wl;
+      *reinterpret_cast<bf16x4*>(DK + 32 + 8 * rg + 4 * fh) = wh;
+      *reinterpret_cast<bf16x4*>(DV + 8 * rg + 4 * fh) = vl;
+      *reinterpret_cast<bf16x4*>(DV + 32 + 8 * rg + 4 * fh) = vh;
+    }
   }
 }
 
@@ -531,16 +572,25 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
     if (db && hipMemsetAsync(db, 0, N * sizeof(float), st) != hipSuccess)
       VY_FAIL(VY_ERR_LAUNCH, "%s: memset failed", who);
   }
-  const int tiles_n = (int)vy_cdiv(N, 128), tiles_k = (int)vy_cdiv(K, 128);
+  // tile 256(n) x 128(k) (8 waves, 11.7 B/kFLOP of L2 traffic) when it still yields enough
+  // (tile, m-split) work items without excessive atomic traffic; else 128 x 128 (4 waves)
+  static const int wv = [] { const char* e = getenv("VY_WGRAD_VARIANT"); return e ? atoi(e) : -1; }();
+  const bool big = wv == 1 || (wv < 0 && N >= 2048);
+  const int BNt = big ? 256 : 128;
+  const int tiles_n = (int)vy_cdiv(N, BNt), tiles_k = (int)vy_cdiv(K, 128);
   const int tiles = tiles_n * tiles_k;
-  int64_t splits = vy_cdiv(384, tiles);                      // ~1.5 workgroups per CU; bounds the atomic bytes
+  int64_t splits = vy_cdiv(big ? 256 : 384, tiles);          // ~1 (big) / ~1.5 (small) workgroups per CU
   const int64_t max_splits = vy_cdiv(M, 256);                // >= 4 stages of 64 rows each
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int64_t m_chunk = vy_cdiv(vy_cdiv(M, splits), 64) * 64;
   splits = vy_cdiv(M, m_chunk);
-  hipLaunchKernelGGL(wgrad_tn_bf16_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
-                     lddy, (const bf16*)x, ldx, dw, lddw, db, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk);
+  if (big)
+    hipLaunchKernelGGL(wgrad_tn_bf16_kernel<256>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, (const bf16*)dy,
+                       lddy, (const bf16*)x, ldx, dw, lddw, db, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk);
+  else
+    hipLaunchKernelGGL(wgrad_tn_bf16_kernel<128>, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
+                       lddy, (const bf16*)x, ldx, dw, lddw, db, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk);
   VY_CHECK_LAUNCH(who);
   return VY_OK;
 }
@@ -551,7 +601,8 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                            int64_t o_sl, const float* lse, float* delta_ws, void* dq, int64_t dq_sb,
                            int64_t dq_sh, int64_t dq_sl, void* dk, int64_t dk_sb, int64_t dk_sh,
                            int64_t dk_sl, void* dv, int64_t dv_sb, int64_t dv_sh, int64_t dv_sl,
-                           int mask_kind, int64_t start_pos, const uint8_t* keypad, int64_t kp_sb, int64_t B,
+                           int mask_kind, int64_t start_pos, const uint8_t* keypad, int64_t kp_sb,
+                           const float* cos_tab, const float* sin_tab, int64_t rope_pos0, int64_t B,
                            int h, int hk, int64_t L, int64_t S, int dh, float scale, int dtype, void* stream) {
   const char* who = "vy_attn_bwd";
   if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only", who);
@@ -575,6 +626,8 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   p.dv = (bf16*)dv; p.dv_sb = dv_sb; p.dv_sh = dv_sh; p.dv_sl = dv_sl;
   p.mask_kind = mask_kind; p.start_pos = (int)start_pos; p.keypad = keypad; p.kp_sb = kp_sb;
   p.B = (int)B; p.h = h; p.hk = hk; p.L = (int)L; p.S = (int)S; p.scale = scale;
+  if ((cos_tab == nullptr) != (sin_tab == nullptr)) VY_FAIL(VY_ERR_ARG, "%s: cos/sin must both be given", who);
+  p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.rope_pos0 = (int)rope_pos0;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)vy_cdiv(B * L, 4)), dim3(256), 0, st, p);
   VY_CHECK_LAUNCH("vy_attn_bwd(delta)");

@@ -20,6 +20,11 @@ namespace {
 template <typename T> struct Chunk;  // one 16-byte chunk = VEC elements
 template <> struct Chunk<bf16> {
   static constexpr int VEC = 8;
+  typedef bf16x8 Raw;
+  static __device__ __forceinline__ void unpack(const Raw& t, float* v) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
   static __device__ __forceinline__ void load(const bf16* p, float* v) {
     bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -34,6 +39,11 @@ template <> struct Chunk<bf16> {
 };
 template <> struct Chunk<float> {
   static constexpr int VEC = 4;
+  typedef f32x4 Raw;
+  static __device__ __forceinline__ void unpack(const Raw& t, float* v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  }
   static __device__ __forceinline__ void load(const float* p, float* v) {
     f32x4 t = *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
@@ -106,6 +116,63 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
+// ---- Gemma RMSNorm: y = x * rsqrt(mean(x^2) + eps) * (1 + w), statistics in fp32 -------------
+// (Examples/paligemma.ipynb cell 11, GemmaRMSNorm)
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const T* __restrict__ x, int64_t ldx,
+                                                          const T* __restrict__ w, T* __restrict__ y, int64_t ldy,
+                                                          int64_t M, int N, float eps, float w_offset) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = N / VEC;
+  float v[CH][VEC];
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      Chunk<T>::load(x + row * ldx + (int64_t)ch * VEC, v[c]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) q += v[c][e] * v[c][e];
+    }
+  }
+  const float ms = vy_wave_sum(q) / (float)N + eps;
+  float r = rsqrtf(ms);
+  r = r * (1.5f - 0.5f * ms * r * r);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      float g[VEC], o[VEC];
+      Chunk<T>::load(w + (int64_t)ch * VEC, g);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = v[c][e] * r * (w_offset + g[e]);
+      Chunk<T>::store(y + row * ldy + (int64_t)ch * VEC, o);
+    }
+  }
+}
+
+// ---- gated activation: out[m, i] = act(gu[m, i]) * gu[m, I + i]  (GeGLU / SwiGLU-style MLPs) ----
+template <typename T, int ACT>
+__global__ void gated_act_kernel(const T* __restrict__ gu, int64_t ldg, T* __restrict__ out, int64_t ldo,
+                                 int64_t M, int I) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int nch = I / VEC;
+  const int64_t total = M * nch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / nch;
+    const int c = (int)(i - m * nch) * VEC;
+    float a[VEC], b[VEC], o[VEC];
+    Chunk<T>::load(gu + m * ldg + c, a);
+    Chunk<T>::load(gu + m * ldg + I + c, b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = vy_act_fwd<ACT>(a[e]) * b[e];
+    Chunk<T>::store(out + m * ldo + c, o);
+  }
+}
+
 // ---- LayerNorm backward -------------------------------------------------------------------
 // wave w of the grid walks rows w, w+W, ...; a lane always owns the same columns, so dgamma /
 // dbeta partials accumulate in registers and are written once per wave into ws[w][N].
@@ -116,8 +183,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     T* __restrict__ dx, int64_t lddx, float* __restrict__ ws, int64_t M, int N, int W) {
   constexpr int VEC = Chunk<T>::VEC;
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= W) return;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);  // W = 4 * gridDim.x waves walk the rows
   const int nch = N / VEC;
   float g[CH][VEC], dg[CH][VEC], db[CH][VEC];
 #pragma unroll
@@ -127,8 +193,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     for (int e = 0; e < VEC; ++e) { dg[c][e] = 0.f; db[c][e] = 0.f; g[c][e] = 0.f; }
     if (ch < nch) Chunk<T>::load(gamma + (int64_t)ch * VEC, g[c]);
   }
+  // software pipeline over the rows of this wave: the 16-byte loads (and the row statistics) of
+  // the NEXT row are issued before the reductions of the current one, so the HBM latency of a row
+  // hides behind the previous row's math instead of serialising with it
+  typedef typename Chunk<T>::Raw Raw;
+  Raw xr[CH], dr[CH], xn[CH], dn[CH];
+  float mu = 0.f, rs = 0.f, mu_n = 0.f, rs_n = 0.f;
+  auto fetch = [&](int64_t row, Raw (&xa)[CH], Raw (&da)[CH], float& m_, float& r_) {
+    m_ = mean[row]; r_ = rstd[row];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        xa[c] = *reinterpret_cast<const Raw*>(x + row * ldx + (int64_t)ch * VEC);
+        da[c] = *reinterpret_cast<const Raw*>(dy + row * lddy + (int64_t)ch * VEC);
+      }
+    }
+  };
+  if (wid < M) fetch(wid, xr, dr, mu, rs);
   for (int64_t row = wid; row < M; row += W) {
-    const float mu = mean[row], rs = rstd[row];
+    const bool more = row + W < M;
+    if (more) fetch(row + W, xn, dn, mu_n, rs_n);
     float xh[CH][VEC], gy[CH][VEC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -136,8 +221,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       const int ch = lane + 64 * c;
       if (ch < nch) {
         float xv[VEC], dv[VEC];
-        Chunk<T>::load(x + row * ldx + (int64_t)ch * VEC, xv);
-        Chunk<T>::load(dy + row * lddy + (int64_t)ch * VEC, dv);
+        Chunk<T>::unpack(xr[c], xv);
+        Chunk<T>::unpack(dr[c], dv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           xh[c][e] = (xv[e] - mu) * rs;
@@ -161,30 +246,60 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         Chunk<T>::store(dx + row * lddx + (int64_t)ch * VEC, o);
       }
     }
+    if (more) {
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { xr[c] = xn[c]; dr[c] = dn[c]; }
+      mu = mu_n; rs = rs_n;
+    }
   }
-  float* wg = ws + (int64_t)wid * N;
-  float* wb = ws + (int64_t)W * N + (int64_t)wid * N;
+  // the block's 4 waves are summed through LDS first, so one slab row per BLOCK is written
+  __shared__ float red[2][3][64 * CH * VEC];
+  const int wv = threadIdx.x >> 6;
+  if (wv > 0) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        red[0][wv - 1][(c * VEC + e) * 64 + lane] = dg[c][e];
+        red[1][wv - 1][(c * VEC + e) * 64 + lane] = db[c][e];
+      }
+  }
+  __syncthreads();
+  if (wv != 0) return;
+  const int WB = W / 4;  // slab rows = blocks
+  float* wg = ws + (int64_t)blockIdx.x * N;
+  float* wb = ws + (int64_t)WB * N + (int64_t)blockIdx.x * N;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int ch = lane + 64 * c;
     if (ch < nch) {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { wg[ch * VEC + e] = dg[c][e]; wb[ch * VEC + e] = db[c][e]; }
+      for (int e = 0; e < VEC; ++e) {
+        float a = dg[c][e], b = db[c][e];
+#pragma unroll
+        for (int w2 = 0; w2 < 3; ++w2) {
+          a += red[0][w2][(c * VEC + e) * 64 + lane];
+          b += red[1][w2][(c * VEC + e) * 64 + lane];
+        }
+        wg[ch * VEC + e] = a; wb[ch * VEC + e] = b;
+      }
     }
   }
 }
 
-// column sums of the [W, N] partial slabs: out = beta*out + sum_w ws[w][n]
-// block = 4 row groups x 64 columns; rows are strided over the groups, then reduced through LDS
+// column sums of the [W, N] partial slabs, accumulated into out0/out1 (zeroed by the launcher
+// when beta == 0): grid = (column blocks of 64) x (row slices), 4 row groups per block reduced
+// through LDS, one fp32 atomic per column per block
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ ws, int W, int N,
                                                               float* __restrict__ out0, float* __restrict__ out1,
-                                                              float beta) {
+                                                              int rows_per_slice) {
   __shared__ float red[2][4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + c;
+  const int w0 = blockIdx.y * rows_per_slice, w1 = min(W, w0 + rows_per_slice);
   float a = 0.f, b = 0.f;
   if (n < N) {
-    for (int w = g; w < W; w += 4) {
+    for (int w = w0 + g; w < w1; w += 4) {
       a += ws[(int64_t)w * N + n];
       b += ws[(int64_t)(W + w) * N + n];
     }
@@ -194,8 +309,8 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
   if (g == 0 && n < N) {
     a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
     b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    if (out0) out0[n] = (beta != 0.f ? beta * out0[n] : 0.f) + a;
-    if (out1) out1[n] = (beta != 0.f ? beta * out1[n] : 0.f) + b;
+    if (out0) atomicAdd(out0 + n, a);
+    if (out1) atomicAdd(out1 + n, b);
   }
 }
 
@@ -424,8 +539,9 @@ int ln_bwd_dispatch(const void* dy, int64_t lddy, const void* x, int64_t ldx, co
   constexpr int VEC = Chunk<T>::VEC;
   if (N % VEC || ldx % VEC || lddy % VEC || lddx % VEC) VY_FAIL(VY_ERR_ARG, "vy_layernorm_bwd: N/ld must be multiples of %d", VEC);
   const int nch = (int)(N / VEC);
-  const int W = (int)vy_layernorm_bwd_ws_rows(M);
-  const dim3 grid((unsigned)vy_cdiv(W, 4)), block(256);
+  const int WB = (int)vy_layernorm_bwd_ws_rows(M);  // blocks = slab rows
+  const int W = WB * 4;
+  const dim3 grid((unsigned)WB), block(256);
 #define LN_GO(CH)                                                                                        \
   hipLaunchKernelGGL((layernorm_bwd_kernel<T, CH>), grid, block, 0, st, (const T*)dy, lddy, (const T*)x, ldx, \
                      (const T*)gamma, mean, rstd, (T*)dx, lddx, ws, M, (int)N, W)
@@ -435,8 +551,16 @@ int ln_bwd_dispatch(const void* dy, int64_t lddy, const void* x, int64_t ldx, co
   else VY_FAIL(VY_ERR_UNSUPPORTED, "vy_layernorm_bwd: N=%ld too wide", (long)N);
 #undef LN_GO
   VY_CHECK_LAUNCH("vy_layernorm_bwd");
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)vy_cdiv(N, 64)), dim3(256), 0, st, ws, W, (int)N,
-                     dgamma, dbeta, beta);
+  if (beta == 0.f) {
+    if (dgamma && hipMemsetAsync(dgamma, 0, N * sizeof(float), st) != hipSuccess) VY_FAIL(VY_ERR_LAUNCH, "vy_layernorm_bwd: memset failed");
+    if (dbeta && hipMemsetAsync(dbeta, 0, N * sizeof(float), st) != hipSuccess) VY_FAIL(VY_ERR_LAUNCH, "vy_layernorm_bwd: memset failed");
+  } else if (beta != 1.f) {
+    VY_FAIL(VY_ERR_ARG, "vy_layernorm_bwd: beta must be 0 or 1");
+  }
+  const int slices = WB >= 64 ? 16 : 1;
+  const int rps = (int)vy_cdiv(WB, slices);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((unsigned)vy_cdiv(N, 64), (unsigned)slices), dim3(256), 0, st, ws, WB,
+                     (int)N, dgamma, dbeta, rps);
   VY_CHECK_LAUNCH("vy_layernorm_bwd(colsum)");
   return VY_OK;
 }
@@ -453,7 +577,56 @@ extern "C" int vy_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, c
   VY_FAIL(VY_ERR_ARG, "vy_layernorm_fwd: bad dtype %d", dtype);
 }
 
-extern "C" int64_t vy_layernorm_bwd_ws_rows(int64_t M) { return M < 512 ? (M < 1 ? 1 : M) : 512; }
+// number of workgroups (= partial slab rows) of the LayerNorm backward: 4 waves each, 16 waves per
+// CU in flight at M = 16384 -- enough outstanding 16-byte loads to stream dy/x at the HBM rate
+extern "C" int vy_rmsnorm_fwd(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int64_t N,
+                              float eps, float w_offset, int dtype, void* stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0) VY_FAIL(VY_ERR_ARG, "vy_rmsnorm_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == VY_BF16 ? 8 : 4;
+  if (N % vec || ldx % vec || ldy % vec) VY_FAIL(VY_ERR_ARG, "vy_rmsnorm_fwd: N/ld must be multiples of %d", vec);
+  const int nch = (int)(N / vec);
+  const dim3 grid((unsigned)vy_cdiv(M, 4)), block(256);
+#define RMS_GO(T, CH) hipLaunchKernelGGL((rmsnorm_fwd_kernel<T, CH>), grid, block, 0, st, (const T*)x, ldx, (const T*)w, (T*)y, ldy, M, (int)N, eps, w_offset)
+#define RMS_DISPATCH(T)                                  \
+  if (nch <= 64) RMS_GO(T, 1);                           \
+  else if (nch <= 128) RMS_GO(T, 2);                     \
+  else if (nch <= 256) RMS_GO(T, 4);                     \
+  else if (nch <= 512) RMS_GO(T, 8);                     \
+  else if (nch <= 1024) RMS_GO(T, 16);                   \
+  else VY_FAIL(VY_ERR_UNSUPPORTED, "vy_rmsnorm_fwd: N=%ld too wide", (long)N)
+  if (dtype == VY_BF16) { RMS_DISPATCH(bf16); }
+  else if (dtype == VY_F32) { RMS_DISPATCH(float); }
+  else VY_FAIL(VY_ERR_ARG, "vy_rmsnorm_fwd: bad dtype %d", dtype);
+#undef RMS_DISPATCH
+#undef RMS_GO
+  VY_CHECK_LAUNCH("vy_rmsnorm_fwd");
+  return VY_OK;
+}
+
+extern "C" int vy_gated_act_fwd(const void* gate_up, int64_t ldg, void* out, int64_t ldo, int64_t M, int64_t I, int act,
+                                int dtype, void* stream) {
+  if (!gate_up || !out || M <= 0 || I <= 0) VY_FAIL(VY_ERR_ARG, "vy_gated_act_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int vec = dtype == VY_BF16 ? 8 : 4;
+  if (I % vec || ldg % vec || ldo % vec) VY_FAIL(VY_ERR_ARG, "vy_gated_act_fwd: I/ld must be multiples of %d", vec);
+  const int64_t want = vy_cdiv(M * (I / vec), 256);
+  const dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
+#define GA_GO(T, A) hipLaunchKernelGGL((gated_act_kernel<T, A>), grid, block, 0, st, (const T*)gate_up, ldg, (T*)out, ldo, M, (int)I)
+  if (dtype == VY_BF16 && act == VY_ACT_GELU_TANH) GA_GO(bf16, VY_ACT_GELU_TANH);
+  else if (dtype == VY_BF16 && act == VY_ACT_GELU_ERF) GA_GO(bf16, VY_ACT_GELU_ERF);
+  else if (dtype == VY_F32 && act == VY_ACT_GELU_TANH) GA_GO(float, VY_ACT_GELU_TANH);
+  else if (dtype == VY_F32 && act == VY_ACT_GELU_ERF) GA_GO(float, VY_ACT_GELU_ERF);
+  else VY_FAIL(VY_ERR_ARG, "vy_gated_act_fwd: unsupported act %d / dtype %d", act, dtype);
+#undef GA_GO
+  VY_CHECK_LAUNCH("vy_gated_act_fwd");
+  return VY_OK;
+}
+
+extern "C" int64_t vy_layernorm_bwd_ws_rows(int64_t M) {
+  const int64_t b = (M + 3) / 4;  // one wave per row at least
+  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+}
 
 extern "C" int vy_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
                                 const float* mean, const float* rstd, void* dx, int64_t lddx, float* dgamma,

@@ -1,0 +1,269 @@
+"""PaliGemma-shaped model (SigLIP vision tower + projector + Gemma decoder) on the HIP kernels.
+
+The reference ships this model only as notebook cells (Examples/paligemma.ipynb cells 9, 11-13,
+15-17); class and parameter names below follow those cells so a checkpoint laid out like the
+notebook's modules loads with ``load_state_dict``.  Same kernels as the VyomAI layers, different
+wiring: pre-norm residual blocks, LayerNorm (SigLIP) / RMSNorm with (1+w) (Gemma), GELU-tanh MLP /
+GeGLU, grouped-query attention down to a single KV head, head_dim 72 (SigLIP) and 256 (Gemma), RoPE
+with theta 10000, embeddings scaled by sqrt(d), LM head tied to the embedding table.
+
+Inference only (config 5 of BASELINE.json is KV-cache decode).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import ACT_GELU_TANH
+from ..layers.positional_embeddings import RopeTable
+
+
+def _packed(mods: List[nn.Linear], cache_owner: nn.Module, key: str):
+    """[W0; W1; ...] (and biases) of sibling projections as one matrix, cached per parameter version."""
+    ver = tuple(m.weight._version for m in mods) + tuple(m.weight.data_ptr() for m in mods)
+    hit = getattr(cache_owner, key, None)
+    if hit is None or hit[0] != ver:
+        w = torch.cat([m.weight.detach() for m in mods], dim=0).contiguous()
+        b = None
+        if mods[0].bias is not None:
+            b = torch.cat([m.bias.detach() for m in mods], dim=0).contiguous()
+        hit = (ver, w, b)
+        setattr(cache_owner, key, hit)
+    return hit[1], hit[2]
+
+
+class SiglipVisionConfig:
+    def __init__(self, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                 num_channels=3, image_size=224, patch_size=16, layer_norm_eps=1e-6, attention_dropout=0.0,
+                 num_image_tokens: int = None, **kwargs):
+        self.hidden_size, self.intermediate_size = hidden_size, intermediate_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.num_channels, self.patch_size, self.image_size = num_channels, patch_size, image_size
+        self.attention_dropout, self.layer_norm_eps = attention_dropout, layer_norm_eps
+        self.num_image_tokens = num_image_tokens
+
+
+class SiglipAttention(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.embed_dim, self.num_heads = config.hidden_size, config.num_attention_heads
+        self.head_dim = self.embed_dim // self.num_heads
+        self.k_proj = nn.Linear(self.embed_dim, self.embed_dim)
+        self.v_proj = nn.Linear(self.embed_dim, self.embed_dim)
+        self.q_proj = nn.Linear(self.embed_dim, self.embed_dim)
+        self.out_proj = nn.Linear(self.embed_dim, self.embed_dim)
+
+
+class SiglipMLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.fc1 = nn.Linear(config.hidden_size, config.intermediate_size)
+        self.fc2 = nn.Linear(config.intermediate_size, config.hidden_size)
+
+
+class SiglipEncoderLayer(nn.Module):
+    """h + out_proj(attn(LN1 h)); h + fc2(gelu_tanh(fc1(LN2 h))).  Notebook cell 9."""
+
+    def __init__(self, config: SiglipVisionConfig):
+        super().__init__()
+        self.embed_dim = config.hidden_size
+        self.self_attn = SiglipAttention(config)
+        self.layer_norm1 = nn.LayerNorm(self.embed_dim, eps=config.layer_norm_eps)
+        self.mlp = SiglipMLP(config)
+        self.layer_norm2 = nn.LayerNorm(self.embed_dim, eps=config.layer_norm_eps)
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        a = self.self_attn
+        B, L, d = hidden_states.shape
+        h, dh = a.num_heads, a.head_dim
+        n, _, _ = ops.layernorm(hidden_states, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
+        w, b = _packed([a.q_proj, a.k_proj, a.v_proj], self, "_qkv")
+        q = torch.empty((B, h, L, dh), dtype=n.dtype, device=n.device)
+        k, v = torch.empty_like(q), torch.empty_like(q)
+        ops.qkv_rope(n, w, b, h, h, dh, None, None, 0, q, k, v)
+        o = ops.attention(q, k, v)
+        x = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=hidden_states)
+        n, _, _ = ops.layernorm(x, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
+        m = ops.linear(n, self.mlp.fc1.weight, self.mlp.fc1.bias, act=ACT_GELU_TANH)
+        return ops.linear(m, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x)
+
+
+class SiglipVisionTransformer(nn.Module):
+    """Patch embedding (stride == kernel conv as one GEMM) + learned positions + N layers + LN."""
+
+    def __init__(self, config: SiglipVisionConfig):
+        super().__init__()
+        self.config = config
+        d, p = config.hidden_size, config.patch_size
+        self.patch_embedding = nn.Conv2d(config.num_channels, d, kernel_size=p, stride=p, padding="valid")
+        self.num_patches = (config.image_size // p) ** 2
+        self.position_embedding = nn.Embedding(self.num_patches, d)
+        self.layers = nn.ModuleList([SiglipEncoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.post_layernorm = nn.LayerNorm(d, eps=config.layer_norm_eps)
+
+    def forward(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        b, c, hh, ww = pixel_values.shape
+        p = self.config.patch_size
+        gh, gw = hh // p, ww // p
+        x = pixel_values.reshape(b, c, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(b, gh * gw, c * p * p)
+        kdim = c * p * p
+        kpad = (kdim + 7) // 8 * 8  # the GEMM wants 16-byte rows (3*14*14 = 588 is fine; keep general)
+        w = self.patch_embedding.weight.reshape(self.patch_embedding.weight.shape[0], -1)
+        if kpad != kdim:
+            x = torch.nn.functional.pad(x, (0, kpad - kdim))
+            w = torch.nn.functional.pad(w, (0, kpad - kdim))
+        hidden = ops.linear(x.contiguous(), w.contiguous(), self.patch_embedding.bias)
+        hidden = hidden + self.position_embedding.weight[None, : gh * gw].to(hidden.dtype)
+        for layer in self.layers:
+            hidden = layer(hidden)
+        y, _, _ = ops.layernorm(hidden, self.post_layernorm.weight, self.post_layernorm.bias, self.post_layernorm.eps)
+        return y
+
+
+class GemmaRMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float = 1e-6):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        return ops.rmsnorm(x, self.weight, self.eps, 1.0)
+
+
+class GemmaMLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.gate_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
+
+    def forward(self, x, residual=None):
+        w, _ = _packed([self.gate_proj, self.up_proj], self, "_gu")
+        gu = ops.linear(x, w)                       # one GEMM for [gate | up]
+        act = ops.gated_act(gu, ACT_GELU_TANH)      # gelu_tanh(gate) * up
+        return ops.linear(act, self.down_proj.weight, residual=residual)
+
+
+class GemmaAttention(nn.Module):
+    def __init__(self, config, layer_idx: Optional[int] = None):
+        super().__init__()
+        self.layer_idx = layer_idx
+        self.hidden_size, self.num_heads, self.head_dim = config.hidden_size, config.num_attention_heads, config.head_dim
+        self.num_key_value_heads = config.num_key_value_heads
+        if self.hidden_size % self.num_heads != 0:
+            raise ValueError(f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size}"
+                             f" and `num_heads`: {self.num_heads}).")
+        bias = config.attention_bias
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=bias)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=bias)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=bias)
+
+
+class GemmaDecoderLayer(nn.Module):
+    """Pre-RMSNorm block with RoPE + GQA/MQA attention and a GeGLU MLP.  Notebook cells 11-13.
+    `cache` is a (k, v) pair of (B, hk, cap, dh) buffers written in place at `start_pos`."""
+
+    def __init__(self, config, layer_idx: int):
+        super().__init__()
+        self.self_attn = GemmaAttention(config=config, layer_idx=layer_idx)
+        self.mlp = GemmaMLP(config)
+        self.input_layernorm = GemmaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = GemmaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, hidden_states: torch.Tensor, rope: Optional[RopeTable], start_pos: int = 0,
+                causal: bool = False, cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+        a = self.self_attn
+        B, L, _ = hidden_states.shape
+        h, hk, dh = a.num_heads, a.num_key_value_heads, a.head_dim
+        n = self.input_layernorm(hidden_states)
+        w, b = _packed([a.q_proj, a.k_proj, a.v_proj], self, "_qkv")
+        cos, sin = rope.on(n.device) if rope is not None else (None, None)
+        q = torch.empty((B, h, L, dh), dtype=n.dtype, device=n.device)
+        if cache is not None:
+            kc, vc = cache
+            kw, vw = kc[:B, :, start_pos:start_pos + L], vc[:B, :, start_pos:start_pos + L]
+        else:
+            kw = torch.empty((B, hk, L, dh), dtype=n.dtype, device=n.device)
+            vw = torch.empty_like(kw)
+        ops.qkv_rope(n, w, b, h, hk, dh, cos, sin, start_pos, q, kw, vw)
+        if cache is not None:
+            k_all, v_all = kc[:B, :, : start_pos + L], vc[:B, :, : start_pos + L]
+        else:
+            k_all, v_all = kw, vw
+        if L == 1:
+            o = ops.attention_decode(q, k_all, v_all, k_all.shape[2])
+        else:
+            o = ops.attention(q, k_all, v_all, causal=causal, start_pos=start_pos)
+        x = ops.linear(o, a.o_proj.weight, a.o_proj.bias, residual=hidden_states)
+        n = self.post_attention_layernorm(x)
+        return self.mlp(n, residual=x)
+
+
+@dataclass
+class PaliGemmaShape:
+    vision: SiglipVisionConfig
+    text: object            # hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, head_dim, ...
+    projection_dim: int
+
+
+class PaliGemmaForConditionalGeneration(nn.Module):
+    """vision_tower -> multi_modal_projector -> [image tokens | text tokens] -> Gemma -> tied LM head.
+    Prefill attends bidirectionally over the whole prefix (the notebook's inference mask,
+    cell 17 `_update_causal_mask` with is_training=False); generated tokens attend to everything
+    before them."""
+
+    def __init__(self, shape: PaliGemmaShape):
+        super().__init__()
+        t = shape.text
+        self.shape = shape
+        self.vision_tower = SiglipVisionTransformer(shape.vision)
+        self.multi_modal_projector = nn.Linear(shape.vision.hidden_size, shape.projection_dim, bias=True)
+        self.embed_tokens = nn.Embedding(t.vocab_size, t.hidden_size)
+        self.layers = nn.ModuleList([GemmaDecoderLayer(t, i) for i in range(t.num_hidden_layers)])
+        self.norm = GemmaRMSNorm(t.hidden_size, eps=t.rms_norm_eps)
+        self.rope = RopeTable(_angles(t.head_dim, t.max_position_embeddings, t.rope_theta))
+
+    def lm_head(self, hidden: torch.Tensor) -> torch.Tensor:
+        return ops.linear(hidden, self.embed_tokens.weight)  # tied (GemmaForCausalLM.tie_weights)
+
+    def _decoder(self, hidden, start_pos, caches):
+        t = self.shape.text
+        hidden = hidden * torch.tensor(t.hidden_size ** 0.5, dtype=hidden.dtype, device=hidden.device)
+        for i, layer in enumerate(self.layers):
+            hidden = layer(hidden, self.rope, start_pos, causal=False, cache=None if caches is None else caches[i])
+        return self.norm(hidden)
+
+    @torch.no_grad()
+    def generate(self, pixel_values: torch.Tensor, input_ids: torch.Tensor, max_new_tokens: int = 64,
+                 max_cache_len: int = 384) -> torch.Tensor:
+        t = self.shape.text
+        dev, dt = pixel_values.device, self.embed_tokens.weight.dtype
+        B = input_ids.shape[0]
+        img = ops.linear(self.vision_tower(pixel_values.to(dt)), self.multi_modal_projector.weight,
+                         self.multi_modal_projector.bias)
+        hidden = torch.cat([img, self.embed_tokens(input_ids)], dim=1)
+        caches = [(torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev),
+                   torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev))
+                  for _ in self.layers]
+        pos = hidden.shape[1]
+        out = self._decoder(hidden, 0, caches)
+        tokens = []
+        nxt = torch.topk(self.lm_head(out[:, -1:, :])[:, -1].float(), k=1, dim=-1)[1]
+        tokens.append(nxt)
+        for _ in range(max_new_tokens - 1):
+            out = self._decoder(self.embed_tokens(nxt), pos, caches)
+            pos += 1
+            nxt = torch.topk(self.lm_head(out)[:, -1].float(), k=1, dim=-1)[1]
+            tokens.append(nxt)
+        return torch.cat(tokens, dim=1)
+
+
+def _angles(dim: int, max_pos: int, base: float) -> torch.Tensor:
+    inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
+    return torch.outer(torch.arange(max_pos).float(), inv)[None]

@@ -226,7 +226,8 @@ def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tens
 
 
 def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, causal: bool, start_pos: int = 0,
-                  keypad: Optional[Tensor] = None, scale: Optional[float] = None) -> None:
+                  keypad: Optional[Tensor] = None, scale: Optional[float] = None,
+                  cos: Optional[Tensor] = None, sin: Optional[Tensor] = None, rope_pos0: int = 0) -> None:
     """Flash attention backward; dq/dk/dv are (B, heads, L|S, dh) views written in place."""
     _need_gpu(q, k, v, out, dout, lse, dq, dk, dv, keypad)
     B, h, L, dh = q.shape
@@ -244,6 +245,7 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, causal: bool, start_po
          dk.data_ptr(), dk.stride(0), dk.stride(1), dk.stride(2),
          dv.data_ptr(), dv.stride(0), dv.stride(1), dv.stride(2),
          kind, start_pos, _ptr(keypad), keypad.stride(0) if keypad is not None else 0,
+         _ptr(cos), _ptr(sin), rope_pos0,
          B, h, hk, L, S, dh, float(scale), dtype_code(q.dtype), _stream())
 
 
@@ -295,3 +297,26 @@ def xent_bwd_(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, 
     M, V = logits2d.shape
     call("vy_xent_bwd", logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), ignore_index, lse.data_ptr(),
          gscale.data_ptr(), count.data_ptr(), M, V, dtype_code(logits2d.dtype), _stream())
+
+
+def rmsnorm(x: Tensor, w: Tensor, eps: float, w_offset: float = 1.0) -> Tensor:
+    """x * rsqrt(mean x^2 + eps) * (w_offset + w)  (vy_rmsnorm_fwd; Gemma: w_offset = 1)."""
+    _need_gpu(x, w)
+    x2 = _rows(x)
+    M, N = x2.shape
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    call("vy_rmsnorm_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), y.data_ptr(), y.stride(0), M, N, float(eps),
+         float(w_offset), dtype_code(x.dtype), _stream())
+    return y.view(x.shape)
+
+
+def gated_act(gate_up: Tensor, act: int) -> Tensor:
+    """act(gate_up[..., :I]) * gate_up[..., I:]  (vy_gated_act_fwd)."""
+    _need_gpu(gate_up)
+    g2 = _rows(gate_up)
+    M, two_i = g2.shape
+    I = two_i // 2
+    out = torch.empty((M, I), dtype=gate_up.dtype, device=gate_up.device)
+    call("vy_gated_act_fwd", g2.data_ptr(), g2.stride(0), out.data_ptr(), out.stride(0), M, I, act,
+         dtype_code(gate_up.dtype), _stream())
+    return out.view(*gate_up.shape[:-1], I)
