@@ -122,10 +122,19 @@ def roofline_probe(cfg, B, L, dev):
     t_blk = event_time_us(block, 10, st)
     f_gemm = 24.0 * d * d * M
     f_blk = block_flops_per_token(d, L) * M
+    # HBM-side bytes per launch come from the committed PMC run (rocprofv3 cannot wrap this process
+    # from the inside): profiles/r01_gemm_pmc.json, same four launches, same shapes
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as f:
+            traffic = round(json.load(f)["avg_hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "bound": "mfma", "kernel": "gemm_nt_bf16_kernel (4 launches of one layer: qkv+rope, out+res, ffn1+gelu, ffn2+res)",
         "achieved": round(f_gemm / t_gemm * 1e-6, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(f_gemm / t_gemm * 1e-6 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        "frac": round(f_gemm / t_gemm * 1e-6 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+        "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01_gemm_pmc.json",
         "avg_launch_us": round(t_gemm / 4, 1), "flops_per_launch": f_gemm / 4,
         "block_forward": {"us": round(t_blk, 1), "achieved": round(f_blk / t_blk * 1e-6, 1),
                           "frac": round(f_blk / t_blk * 1e-6 / PEAK_BF16_TFLOPS, 4),
