@@ -320,7 +320,9 @@ class LMHeadLossFn(torch.autograd.Function):
         n, mean, rstd = ops.layernorm(g, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
         V = wv.shape[0]
         ld = (V + 7) // 8 * 8
-        buf = torch.zeros((B * L, ld), dtype=dt, device=dev)
+        buf = torch.empty((B * L, ld), dtype=dt, device=dev)
+        if ld != V:
+            buf[:, V:].zero_()  # only the pad columns: the GEMM writes the rest
         logits = buf[:, :V]
         ops.linear(n.view(B * L, -1), _shadow(wv, dt), _shadow(bias, dt), out=logits)
         shifted = torch.full((B, L), ignore_index, dtype=torch.long, device=dev)

@@ -1,7 +1,7 @@
 // Scaled-dot-product attention forward for the VyomAI hot path.
 //
 // attn_fwd_mfma_kernel (bf16, dh in {64,128}): flash-style, one workgroup = 4 waves = 128 query
-// rows of one (batch, head); K/V tiles of 64 keys are staged by LDS-DMA (double buffered).
+// rows of one (batch, head); K/V tiles of 64 keys are staged by LDS-DMA through a 3-deep ring.
 //   * "swapped" QK^T: S^T = K.Q^T (A operand = K rows read with ds_read_b128 from an XOR-swizzled
 //     [key][d] image, B operand = Q kept in registers), so each lane owns ONE query row and its
 //     softmax statistics; the row max/sum need one cross-half exchange (lane ^ 32) only;
@@ -12,8 +12,8 @@
 //     transposed read hit distinct banks;
 //   * GQA: kv head = q head / (h/hk) -- repeat_kv is never materialised;
 //   * masks are descriptors, not tensors: causal offset, key-padding bytes, or a generic additive
-//     fp32 mask.  Masked scores take -FLT_MAX exactly like the reference's additive
-//     (1-mask)*finfo.min (the score is absorbed), so a fully masked row averages V over all keys.
+//     fp32 mask.  The reference's masked score is finfo.min (the score is absorbed): it weighs
+//     exactly 0 next to any visible key, and a row with no visible key averages V over all keys.
 //
 // attn_rowwise_kernel (f32 / any dh, and the L==1 decode path): one workgroup per query row, a
 // single online-softmax pass over K and V with 16-byte coalesced loads, no LDS score buffer.
@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   constexpr int NP = TILE / 1024 / 4;   // 1-KiB LDS-DMA pieces per wave per tile
   constexpr int KS = DH / 16;           // k-steps of the QK^T contraction
   constexpr int ND = DH / 32;           // 32-wide d blocks of O^T
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // K0 K1 V0 V1
+  constexpr int NS = 3;                 // K/V tiles in the LDS ring: NS - 1 tiles of loads in flight
+  constexpr int KPW = 256;              // key-padding visibility words (64 keys each): S <= 16384
+  // ONE shared object (a second one makes hipcc wait vmcnt(0) before every ds_read while LDS-DMA
+  // is in flight): K ring, V ring, then 4 flag words for the block-wide OR below
+  __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE + 64 + KPW * 8];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
       __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)ks,
                                        (VY_LDS void*)(smem + buf * TILE + (wave * NP + t) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)vs,
-                                       (VY_LDS void*)(smem + (2 + buf) * TILE + (wave * NP + t) * 1024), 16, 0, 0);
+                                       (VY_LDS void*)(smem + (NS + buf) * TILE + (wave * NP + t) * 1024), 16, 0, 0);
     }
   };
 
@@ -118,12 +122,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   for (int n = 0; n < ND; ++n)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  // running max in scaled log2 units.  Always finite: a masked score is -inf here (it contributes
+  // exactly 0, as exp(finfo.min - m) does in the reference whenever the row has a visible key);
+  // rows with NO visible key are recognised by l == 0 after the loop and get the reference's
+  // uniform average over all keys from the column-sum pass below.
+  float m_run = -FLT_MAX, l_run = 0.f;
   const float c = p.scale * LOG2E;
 
-  // tile range.  Pure causal: keys beyond the diagonal of the block's last row are never
-  // visible -> skipped.  With a key-padding mask a row can be fully masked; the reference then
-  // averages V over ALL keys, so the loop is extended to S when that happens (see below).
+  // pure causal: keys beyond the diagonal of the block's last row are never visible -> skipped
   const int nt_all = (p.S + 63) / 64;
   int nt = nt_all;
   if (causal) {
@@ -133,12 +139,25 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   }
   const int wave_first = q0 + wave * 32, wave_last = wave_first + 31;
 
+  // key-padding mask -> one 64-bit visibility word per key tile, built once (an ordinary load inside
+  // the tile loop would make the compiler drain the LDS-DMA ring with vmcnt(0) every tile)
+  unsigned long long* kpbits = reinterpret_cast<unsigned long long*>(smem + 2 * NS * TILE + 64);
+  if (haskp) {
+    for (int t = wave; t < nt; t += 4) {
+      const int kj = t * 64 + lane;
+      const bool vis = kj < p.S && kp[kj < p.S ? kj : 0] != 0;
+      const unsigned long long bits = __ballot(vis);
+      if (lane == 0) kpbits[t] = bits;
+    }
+    __syncthreads();
+  }
+
   auto compute = [&](int tile, int buf) {
     const int k0 = tile * 64;
-    // wave-uniform skip of tiles wholly above this wave's diagonal (pure causal only)
-    if (causal && !haskp && !hasadd && k0 > p.start_pos + wave_last) return;
+    // wave-uniform skip of tiles wholly above this wave's diagonal
+    if (causal && k0 > p.start_pos + wave_last) return;
     const char* kb_ = smem + buf * TILE;
-    const char* vb_ = smem + (2 + buf) * TILE;
+    const char* vb_ = smem + (NS + buf) * TILE;
     f32x16 st[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -150,22 +169,34 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
       }
     }
-    const bool need_mask = haskp || hasadd || (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first);
+    unsigned long long vis = ~0ull;
+    if (haskp) vis = kpbits[tile];
+    const bool need_mask = hasadd || (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first) || vis != ~0ull;
+    // softmax runs on the RAW scores: max first, then p = exp2(fma(s, c, -m)) -- one FMA and one
+    // v_exp_f32 per element (the VALU, not the MFMA pipe, bounds dh=64)
     float tmax = -INFINITY;
     if (need_mask) {
+      // key index of register r is k0 + 4fh + kofs, kofs = 32kb + (r&3) + 8(r>>2).  Visibility of
+      // the lane's 32 keys as one bit word: padding bits shifted by 4fh, AND kofs <= klim (causal
+      // diagonal and end of sequence)
+      int klim = p.S - 1 - k0 - 4 * fh;
+      if (causal) klim = min(klim, qi + p.start_pos - k0 - 4 * fh);
+      unsigned long long lm = klim >= 63 ? ~0ull : (klim < 0 ? 0ull : ((2ull << klim) - 1ull));
+      lm &= vis >> (4 * fh);
+      const unsigned lmw[2] = {(unsigned)lm, (unsigned)(lm >> 32)};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int kj = k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          float t = st[kb][r] * c;
-          if (kj < p.S) {
-            if (hasadd) t = fmaxf(t + am[kj] * LOG2E, -FLT_MAX);
-            if (causal && kj > qi + p.start_pos) t = -FLT_MAX;
-            if (haskp && !kp[kj]) t = -FLT_MAX;
-          } else {
-            t = -INFINITY;  // beyond the sequence: contributes nothing, ever
+          const int bit = (r & 3) + 8 * (r >> 2);
+          float t = st[kb][r];
+          if (hasadd) {
+            // in-range guard only: invisible keys are overwritten below
+            const int kj = min(k0 + 4 * fh + 32 * kb + bit, p.S - 1);
+            t += am[kj] * (LOG2E / c);
+            if (!(t > -FLT_MAX)) t = -INFINITY;  // finfo.min-style additive masks absorb the score
           }
+          t = ((lmw[kb] >> bit) & 1u) ? t : -INFINITY;
           st[kb][r] = t;
           tmax = fmaxf(tmax, t);
         }
@@ -173,29 +204,34 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          st[kb][r] *= c;
-          tmax = fmaxf(tmax, st[kb][r]);
-        }
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, st[kb][r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);  // finite: every tile holds >= 1 in-range key
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
-    float rs = 0.f;
+    const float tmax_s = tmax * c;  // -inf stays -inf
+    // lazy rescale: the running max is only raised (and O, l rescaled) when some row of the wave
+    // would otherwise see p > 2^8; exp2 arguments stay <= 8, harmless for fp32 sums and bf16 P
+    if (__any(tmax_s > m_run + 8.f)) {
+      const float m_new = fmaxf(m_run, tmax_s);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+    }
+    const float neg_m = -m_run;
+    float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(st[kb][r] - m_new);
-        st[kb][r] = e;
-        rs += e;
+      for (int r = 0; r < 16; r += 2) {
+        const float e0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, neg_m));
+        const float e1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], c, neg_m));
+        st[kb][r] = e0; st[kb][r + 1] = e1;
+        rs0 += e0; rs1 += e1;
       }
-    l_run = l_run * alpha + rs;  // per-half partial; halves are summed at the end
-#pragma unroll
-    for (int n = 0; n < ND; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+    l_run += rs0 + rs1;  // per-half partial; halves are summed at the end
     // P fragments: registers 8s..8s+7 of block kb <-> keys 32kb+16s+8(j>>2)+4h+(j&3)
     bf16x8 pf[2][2];
 #pragma unroll
@@ -220,32 +256,78 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
         }
   };
 
-  // single tile loop (one inlined call site of compute(): the accumulators stay in registers).
-  // With a key-padding mask a row whose visible keys are all padding has m == -FLT_MAX; the
-  // reference's softmax over [finfo.min, ...] is then uniform over EVERY key, so the loop is
-  // extended over the causally skipped tiles when any row of the block is in that state.
-  int t = 0, t_end = nt;
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  while (true) {
-    for (; t < t_end; ++t) {
-      if (t + 1 < t_end) stage(t + 1, (t + 1) & 1);
-      compute(t, t & 1);
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
+  // Loads run NS-1 tiles ahead of the MFMAs: a tile is waited for with a COUNTED vmcnt (its own
+  // 2*NP LDS-DMA instructions are the oldest outstanding ones of the wave) and one raw s_barrier per
+  // tile; nothing in the loop drains the memory pipe, so the L2/HBM latency of a tile is covered
+  // by the softmax + MFMA work of the previous tiles instead of being paid once per tile.
+  auto wait_tile = [&](int younger) {
+    if (younger >= 1) {
+      if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (t_end < nt_all && haskp && __syncthreads_or(m_run == -FLT_MAX && qi < p.L)) {
-      t_end = nt_all;
-      stage(t, t & 1);
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      continue;
-    }
-    break;
+  };
+  // The Q fragments came through ordinary loads: make the compiler retire them HERE (an asm that
+  // reads them), before any LDS-DMA is in flight -- otherwise its wait for them sits at the first
+  // MFMA inside the loop as vmcnt(0) and drains the ring every tile.
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+#pragma unroll
+  for (int s_ = 0; s_ < NS - 1; ++s_)
+    if (s_ < nt) stage(s_, s_);
+  for (int t = 0; t < nt; ++t) {
+    wait_tile(min(NS - 2, nt - 1 - t));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + NS - 1 < nt) stage(t + NS - 1, (t + NS - 1) % NS);  // the buffer tile t-1 was read from
+    compute(t, t % NS);
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (haskp || hasadd) {
+    // Rows without a single visible key: the reference's softmax over [finfo.min, ...] is uniform
+    // over EVERY key (causally hidden ones too), i.e. the output is the column mean of V.  Block-wide
+    // OR of "one of my rows is such a row" through the flag words, then a cooperative column sum.
+    int* flags = reinterpret_cast<int*>(smem + 2 * NS * TILE);
+    const bool dead = l_tot == 0.f;
+    const bool mine = __any(dead && qi < p.L);
+    __builtin_amdgcn_s_barrier();  // every wave is done with the ring
+    if (lane == 0) flags[wave] = mine ? 1 : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if ((flags[0] | flags[1] | flags[2] | flags[3]) != 0) {
+      constexpr int NCH = DH / 8, NSL = 256 / NCH;
+      float* part = reinterpret_cast<float*>(smem);              // [NSL][DH]
+      float* colsum = part + NSL * DH;                           // [DH]
+      const int ch = tid % NCH, sl = tid / NCH;
+      float a8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a8[e] = 0.f;
+      for (int kj = sl; kj < p.S; kj += NSL) {
+        const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(Vb + (int64_t)kj * p.v_sl + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a8[e] += (float)v8[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part[sl * DH + ch * 8 + e] = a8[e];
+      __syncthreads();
+      if (tid < DH) {
+        float sacc = 0.f;
+        for (int s_ = 0; s_ < NSL; ++s_) sacc += part[s_ * DH + tid];
+        colsum[tid] = sacc;
+      }
+      __syncthreads();
+      if (dead) {
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[n][r] = colsum[32 * n + 8 * (r >> 2) + (r & 3) + 4 * fh];
+        l_tot = (float)p.S;
+        m_run = -FLT_MAX;
+      }
+    }
+  }
   const float inv = 1.0f / l_tot;
   if (qi < p.L) {
     bf16* O = (bf16*)p.out + (int64_t)b * p.o_sb + (int64_t)qi * p.o_sl + head * DH;
@@ -462,7 +544,8 @@ extern "C" int vy_attn_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
   if (int rc = check_attn(who, p, dh, dtype)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VY_BF16 && (dh == 64 || dh == 128) && L > 1) {
+  // (the key-padding visibility words of the MFMA kernel cover 16384 keys)
+  if (dtype == VY_BF16 && (dh == 64 || dh == 128) && L > 1 && !((mask_kind & VY_MASK_KEYPAD) && S > 16384)) {
     const dim3 grid((unsigned)((L + 127) / 128), (unsigned)h, (unsigned)B), block(256);
     if (dh == 64) hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_mfma_kernel<128>, grid, block, 0, st, p);

@@ -18,6 +18,34 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define VY_LDS __attribute__((address_space(3)))
 #define VY_GLOBAL __attribute__((address_space(1)))
 
+// ---- transposing LDS reads that the compiler's waitcnt pass cannot see ----------------------
+// hipcc cannot tell what the ds_read_b64_tr_b16 *builtin* aliases, so whenever LDS-DMA
+// (global_load ... lds, counted by vmcnt) is in flight it puts s_waitcnt vmcnt(0) in front of the
+// read: the prefetch of the next tile is drained before the current tile's MFMAs even start.
+// The asm form is invisible to that pass.  Its result is NOT tracked either: retire the reads with
+// vy_lgkm_wait<N>(frags...) (N = LDS reads issued after the ones needed) before the first use.
+// A compiler-issued lgkmcnt wait in between only ever over-waits (LDS returns in order).
+__device__ __forceinline__ s16x4 vy_lds_tr16(const char* p) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"((unsigned)(uintptr_t)(VY_LDS const char*)p) : "memory");
+  return r;
+}
+// rows r and r+8 of a transposed 16-row block -> one MFMA A/B fragment (2 LDS reads, no wait)
+__device__ __forceinline__ bf16x8 vy_lds_tr16_pair(const char* p0, const char* p1) {
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = vy_lds_tr16(p0);
+  u.s.b = vy_lds_tr16(p1);
+  return u.v;
+}
+template <typename T>
+__device__ __forceinline__ void vy_tie(T& v) { asm volatile("" : "+v"(v)); }
+template <int N, typename... T>
+__device__ __forceinline__ void vy_lgkm_wait(T&... v) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  // tie every fragment to this point: the MFMAs that read them cannot be scheduled above the wait
+  (vy_tie(v), ...);
+}
+
 // host-side error plumbing -------------------------------------------------------------
 void vy_set_error(const char* fmt, ...);
 #define VY_FAIL(code, ...)      \

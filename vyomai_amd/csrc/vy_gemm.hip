@@ -499,13 +499,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
 // ------------------------------------------------------------------------------------------
 #define VY_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-template <int BN, int EPI, int ACT, bool GRAD, int VAR>
+template <int BN, int EPI, int ACT, bool GRAD, int VAR, int NS>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
     int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
   constexpr int BM = 256, WGM = 4, WGN = 2, NW = 8;
   constexpr int TM = 2, TN = BN / 64;
-  constexpr int RK = 32, RROW = 64, NS = 4;
+  constexpr int RK = 32, RROW = 64;  // NS slices in the LDS ring, NS - 1 in flight
   constexpr int PX = BM / 16, PW = BN / 16;          // 1-KiB pieces (16 rows x 64 B) per slice
   constexpr int GX = PX / NW, GW = (PW + NW - 1) / NW;  // per wave: 2 and 2 (the last may be absent)
   constexpr int STAGE = (BM + BN) * RROW;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
 
   // one LDS-DMA piece of slice kt: pieces 0..GX-1 are X, GX..GX+GW-1 are W
   auto stage_piece = [&](int kt, int pc) {
-    char* xb = smem + (kt & (NS - 1)) * STAGE;
+    char* xb = smem + (kt % NS) * STAGE;
     char* wb = xb + BM * RROW;
     const int k0 = kt * RK;
     if (pc < GX) {
@@ -584,14 +584,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
   const int wrow_off = (wn * 32 * TN + fr) * RROW;
 
   auto wait_landed = [&](int younger) {  // all but the loads of `younger` later slices are done
-    if (w_last) {
-      if (younger >= 2) VY_WAIT_VM(8); else if (younger == 1) VY_WAIT_VM(4); else VY_WAIT_VM(0);
-    } else {
-      if (younger >= 2) VY_WAIT_VM(6); else if (younger == 1) VY_WAIT_VM(3); else VY_WAIT_VM(0);
+    if (w_last) {  // GX + GW = 4 loads per slice
+      if (younger >= 3) VY_WAIT_VM(12); else if (younger == 2) VY_WAIT_VM(8); else if (younger == 1) VY_WAIT_VM(4); else VY_WAIT_VM(0);
+    } else {       // one W piece less
+      if (younger >= 3) VY_WAIT_VM(9); else if (younger == 2) VY_WAIT_VM(6); else if (younger == 1) VY_WAIT_VM(3); else VY_WAIT_VM(0);
     }
   };
   auto read_frags = [&](int kt, int ks, bf16x8 (&wf)[TN], bf16x8 (&xf)[TM]) {
-    const char* xb = smem + (kt & (NS - 1)) * STAGE;
+    const char* xb = smem + (kt % NS) * STAGE;
     const char* wb = xb + BM * RROW;
     const int coff = (((ks * 2 + fh) ^ fsw) << 4);
 #pragma unroll
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
 
   if constexpr (VAR == 0) {
     for (int kt = 0; kt < KT; ++kt) {
-      wait_landed(min(2, KT - 1 - kt));
+      wait_landed(min(NS - 2, KT - 1 - kt));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (kt + NS - 1 < KT) stage(kt + NS - 1);  // refills the buffer every wave finished reading
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
     // MFMAs first: the matrix pipe starts right after the barrier, the LDS-DMA issue of the
     // slice three ahead rides in the shadow of the first k-step's MFMAs
     for (int kt = 0; kt < KT; ++kt) {
-      wait_landed(min(2, KT - 1 - kt));
+      wait_landed(min(NS - 2, KT - 1 - kt));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       bf16x8 wf[TN], xf[TM], wf1[TN], xf1[TM];
@@ -864,13 +864,16 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
     } else if (var == 1) {
-      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 1>), dim3(tm * tn), dim3(512), 0,
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 1, 4>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
     } else if (var == 2) {
-      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 2>), dim3(tm * tn), dim3(512), 0,
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 2, 4>), dim3(tm * tn), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    } else if (var == 5) {
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 0, 5>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
     } else {
-      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 0>), dim3(tm * tn), dim3(512), 0,
+      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 0, 4>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
     }
   }
