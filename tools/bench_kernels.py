@@ -78,6 +78,14 @@ def main():
     rows.append(("attn causal (causal-counted flops)", t, 2.0 * B * h * L * L * dh / t * 1e-6))
     t = timeit(lambda: ops.attention(q, k, v, causal=False, out=o), a.iters)
     rows.append(("attn full", t, 4.0 * B * h * L * L * dh / t * 1e-6))
+    # attention backward (delta + dq + dkdv), causal
+    o4 = torch.empty(B, L, h, dh, dtype=bf, device=dev)
+    lse = torch.empty(B, h, L, dtype=torch.float32, device=dev)
+    ops.attention(q, k, v, causal=True, out=o4.view(B, L, d), lse=lse)
+    do = r(B, L, h, dh)
+    dq_, dk_, dv_ = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    t = timeit(lambda: ops.attention_bwd(q, k, v, o4.view(B, L, d), do.view(B, L, d), lse, dq_, dk_, dv_, causal=True), a.iters)
+    rows.append(("attn bwd causal (causal-counted flops)", t, 5.0 * B * h * L * L * dh / t * 1e-6))
     # layernorm
     gma, bta = r(d), r(d)
     t = timeit(lambda: ops.layernorm(x, gma, bta, 1e-5), a.iters)

@@ -240,20 +240,24 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[kb][s][j] = (bf16)st[kb][8 * s + j];
+    // V^T fragments: asm transposing reads (see vy_common.h), one fragment ahead of its MFMA
+    auto vfrag = [&](int f) {
+      const int n = f >> 2, kb = (f >> 1) & 1, s = f & 1;
+      const char* a_ = vb_ + (32 * kb + 16 * s + v_lane_row) * RB + ((64 * n + v_lane_off) ^ v_sw);
+      return vy_lds_tr16_pair(a_, a_ + 8 * RB);
+    };
+    bf16x8 vfr[2];
+    vfr[0] = vfrag(0);
 #pragma unroll
-    for (int n = 0; n < ND; ++n)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int row = 32 * kb + 16 * s + v_lane_row;
-          const int off = (64 * n + v_lane_off) ^ v_sw;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(vb_ + row * RB + off));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(vb_ + (row + 8) * RB + off));
-          union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-          u.s.a = lo; u.s.b = hi;
-          o[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pf[kb][s], o[n], 0, 0, 0);
-        }
+    for (int f = 0; f < 4 * ND; ++f) {
+      if (f + 1 < 4 * ND) {
+        vfr[(f + 1) & 1] = vfrag(f + 1);
+        vy_lgkm_wait<2>(vfr[f & 1]);
+      } else {
+        vy_lgkm_wait<0>(vfr[f & 1]);
+      }
+      o[f >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[f & 1], pf[(f >> 1) & 1][f & 1], o[f >> 2], 0, 0, 0);
+    }
   };
 
   // Loads run NS-1 tiles ahead of the MFMAs: a tile is waited for with a COUNTED vmcnt (its own

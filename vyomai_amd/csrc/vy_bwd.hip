@@ -237,7 +237,7 @@ struct BwdParams {
   const float* cos_tab; const float* sin_tab; int rope_pos0;  // NULL: no RoPE backward fused
 };
 
-// delta[b,h,q] = sum_d dO[b,q,h*dh+d] * O[b,q,h*dh+d]; one wave per (b,q) row, dh = 64
+// delta_ws[b,h,q] = -sum_d dO[b,q,h*dh+d] * O[b,q,h*dh+d]; one wave per (b,q) row, dh = 64
 __global__ __launch_bounds__(256) void attn_delta_kernel(BwdParams p) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(BwdParams p) {
       for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)d[e];
     }
     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    if (c < nch && (c & 7) == 0) p.delta[((int64_t)b * p.h + (c >> 3)) * p.L + qi] = s;
+    if (c < nch && (c & 7) == 0) p.delta[((int64_t)b * p.h + (c >> 3)) * p.L + qi] = -s;  // NEGATED: it is the dP accumulator's initial value
   }
 }
 
@@ -281,10 +281,19 @@ __device__ __forceinline__ int dual_sw(int row) {
   return ((v & 1) << 2) | (v >> 1);
 }
 
+// visibility bits [lo, hi) of a 32- or 64-wide index range (lo/hi may lie outside it)
+__device__ __forceinline__ unsigned long long range_bits64(int lo, int hi) {
+  const unsigned long long up = hi >= 64 ? ~0ull : (hi <= 0 ? 0ull : ((1ull << hi) - 1ull));
+  const unsigned long long dn = lo >= 64 ? 0ull : (lo <= 0 ? ~0ull : (~0ull << lo));
+  return up & dn;
+}
+
 // ---- dq kernel: forward structure, no online softmax --------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
-  constexpr int DH = 64, RB = 128, TILE = 64 * RB;
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // K0 K1 V0 V1
+// K/V tiles of 64 keys run through a 3-deep LDS-DMA ring with counted vmcnt waits (as in the
+// forward kernel); masks are per-lane bit words, P is recomputed as exp2(fma(s, c, -lse*log2e)).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdParams p) {
+  constexpr int DH = 64, RB = 128, TILE = 64 * RB, NS = 3, KPW = 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE + KPW * 8];  // K ring, V ring, key-padding words
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (p.L + 127) / 128;
@@ -307,8 +316,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
   }
   const int64_t stat = ((int64_t)b * p.h + head) * p.L + qrow;
   const float c = p.scale * LOG2E;
-  const float neg_lse = -p.lse[stat] * LOG2E;  // p = exp2(c*s + neg_lse)
-  const float neg_delta = -p.delta[stat];
+  float neg_lse = -p.lse[stat] * LOG2E;  // p = exp2(c*s + neg_lse)
+  float neg_delta = p.delta[stat];       // the delta kernel stores -delta
   const bool causal = p.mask_kind & VY_MASK_CAUSAL;
   const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
   const uint8_t* kp = haskp ? p.keypad + (int64_t)b * p.kp_sb : nullptr;
@@ -331,12 +340,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
       __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(Kb + (int64_t)kr * p.k_sl + ld_koff[t]),
                                        (VY_LDS void*)(smem + buf * TILE + (wave * 2 + t) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(Vb + (int64_t)kr * p.v_sl + ld_voff[t]),
-                                       (VY_LDS void*)(smem + (2 + buf) * TILE + (wave * 2 + t) * 1024), 16, 0, 0);
+                                       (VY_LDS void*)(smem + (NS + buf) * TILE + (wave * 2 + t) * 1024), 16, 0, 0);
     }
   };
   const int k_sw = dual_sw(fr), v_sw = (fr >> 1) & 7;
   const int li = lane & 15, g16 = (lane >> 4) & 1;
   const int t_row = 4 * fh + (li >> 2);
+  const int t_chunk = 2 * g16 + ((li & 3) >> 1), t_byte = 8 * (li & 1);
 
   f32x16 dq[2];
 #pragma unroll
@@ -345,65 +355,101 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
     for (int r = 0; r < 16; ++r) dq[n][r] = 0.f;
 
   int nt = (p.S + 63) / 64;
-  if (causal) nt = min(nt, (min(p.S, p.start_pos + q0 + 128) + 63) / 64);
+  if (causal) nt = max(1, min(nt, (min(p.S, p.start_pos + q0 + 128) + 63) / 64));
   const int wave_first = q0 + wave * 32, wave_last = wave_first + 31;
 
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1, k0 = t * 64;
-    if (t + 1 < nt) stage(t + 1, buf ^ 1);
-    if (!(causal && k0 > p.start_pos + wave_last)) {
-      const char* kb_ = smem + buf * TILE;
-      const char* vb_ = smem + (2 + buf) * TILE;
-      f32x16 st[2], dp[2];
+  unsigned long long* kpbits = reinterpret_cast<unsigned long long*>(smem + 2 * NS * TILE);
+  if (haskp) {
+    for (int t = wave; t < nt; t += 4) {
+      const int kj = t * 64 + lane;
+      const bool vis = kj < p.S && kp[kj < p.S ? kj : 0] != 0;
+      const unsigned long long bits = __ballot(vis);
+      if (lane == 0) kpbits[t] = bits;
+    }
+    __syncthreads();
+  }
+
+  auto compute = [&](int tile, int buf) {
+    const int k0 = tile * 64;
+    if (causal && k0 > p.start_pos + wave_last) return;
+    const char* kb_ = smem + buf * TILE;
+    const char* vb_ = smem + (NS + buf) * TILE;
+    f32x16 st[2], dp[2];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = neg_delta; }
+      for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = neg_delta; }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ k_sw) << 4));
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ v_sw) << 4));
-          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
-          dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], dp[kb], 0, 0, 0);
-        }
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ k_sw) << 4));
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ v_sw) << 4));
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+        dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], dp[kb], 0, 0, 0);
       }
-      const bool need_mask = haskp || (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first);
-      bf16x8 ds[2][2];
+    }
+    unsigned long long vis = ~0ull;
+    if (haskp) vis = kpbits[tile];
+    const bool need_mask = (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first) || vis != ~0ull;
+    bf16x8 ds[2][2];
+    if (need_mask) {
+      // key of register r: k0 + 4fh + kofs, kofs = 32kb + (r&3) + 8(r>>2); visible iff kofs <= klim
+      int klim = p.S - 1 - k0 - 4 * fh;
+      if (causal) klim = min(klim, qi + p.start_pos - k0 - 4 * fh);
+      const unsigned long long lm = range_bits64(0, klim + 1) & (vis >> (4 * fh));
+      const unsigned lmw[2] = {(unsigned)lm, (unsigned)(lm >> 32)};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float pr = exp2f(st[kb][r] * c + neg_lse);
-          if (need_mask) {
-            const int kj = k0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (kj >= p.S || (causal && kj > qi + p.start_pos) || (haskp && !kp[kj])) pr = 0.f;
-          }
+          float pr = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, neg_lse));
+          pr = ((lmw[kb] >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pr : 0.f;
           ds[kb][r >> 3][r & 7] = (bf16)(pr * dp[kb][r]);
         }
-      // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+    } else {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int row = 32 * kb + 16 * s + t_row;
-            const int chunk = 4 * n + 2 * g16 + ((li & 3) >> 1);
-            // rows row and row+8 share dual_sw's low-order behaviour only through (row>>1)&7:
-            const char* a0 = kb_ + row * RB + ((chunk ^ dual_sw(row)) << 4) + 8 * (li & 1);
-            const char* a1 = kb_ + (row + 8) * RB + ((chunk ^ dual_sw(row + 8)) << 4) + 8 * (li & 1);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)a0);
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)a1);
-            union { struct { s16x4 a, b; } s_; bf16x8 v; } u;
-            u.s_.a = lo; u.s_.b = hi;
-            dq[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, ds[kb][s], dq[n], 0, 0, 0);
-          }
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, neg_lse));
+          ds[kb][r >> 3][r & 7] = (bf16)(pr * dp[kb][r]);
+        }
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
+    // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]; K^T fragments by asm transposing reads, one ahead
+    auto kfrag = [&](int f) {
+      const int n = f >> 2, row = 32 * ((f >> 1) & 1) + 16 * (f & 1) + t_row;
+      const int chunk = 4 * n + t_chunk;
+      return vy_lds_tr16_pair(kb_ + row * RB + ((chunk ^ dual_sw(row)) << 4) + t_byte,
+                              kb_ + (row + 8) * RB + ((chunk ^ dual_sw(row + 8)) << 4) + t_byte);
+    };
+    bf16x8 kfr[2];
+    kfr[0] = kfrag(0);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      if (f + 1 < 8) {
+        kfr[(f + 1) & 1] = kfrag(f + 1);
+        vy_lgkm_wait<2>(kfr[f & 1]);
+      } else {
+        vy_lgkm_wait<0>(kfr[f & 1]);
+      }
+      dq[f >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[f & 1], ds[(f >> 1) & 1][f & 1], dq[f >> 2], 0, 0, 0);
+    }
+  };
+
+  // every ordinary load is retired before the first LDS-DMA (else the compiler's wait for it
+  // becomes a vmcnt(0) inside the loop and drains the ring every tile)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { vy_tie(qf[ks]); vy_tie(gf[ks]); }
+  vy_tie(neg_lse); vy_tie(neg_delta);
+#pragma unroll
+  for (int s_ = 0; s_ < NS - 1; ++s_)
+    if (s_ < nt) stage(s_, s_);
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + NS - 1 < nt) stage(t + NS - 1, (t + NS - 1) % NS);
+    compute(t, t % NS);
   }
   if (qi < p.L) {
     bf16* D = p.dq + (int64_t)b * p.dq_sb + (int64_t)head * p.dq_sh + (int64_t)qi * p.dq_sl;
@@ -424,11 +470,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdParams p) {
 
 // ---- dk/dv kernel ----------------------------------------------------------------------------
 // workgroup = 128 keys of one (batch, kv head); wave w owns keys [k0+32w, +32) and keeps dK^T and
-// dV^T for them in registers while the workgroup sweeps (query head of the group) x (32-row query
-// tile); Q and dO tiles are staged by LDS-DMA into dual-use images (row + transposed reads).
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(BwdParams p) {
-  constexpr int DH = 64, RB = 128, QT = 32 * RB;  // one 32-row tile = 4 KiB
-  __shared__ __attribute__((aligned(16))) char smem[4 * QT];  // Q0 Q1 dO0 dO1
+// dV^T for them in registers while the workgroup sweeps (query head of the group) x (64-row query
+// tile).  Q and dO tiles are staged by LDS-DMA into dual-use images (row + transposed reads)
+// through a 3-deep ring; the tile's row statistics (lse, -delta) ride along as one 4-byte-per-lane
+// LDS-DMA per wave, so the loop holds no ordinary load and is paced by counted vmcnt waits only.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(BwdParams p) {
+  constexpr int DH = 64, RB = 128, QR = 64, QT = QR * RB, NS = 3;  // one 64-row tile = 8 KiB
+  constexpr int ST_OFF = 2 * NS * QT;                              // NS x [lse 64 floats][-delta 64 floats]
+  __shared__ __attribute__((aligned(16))) char smem[2 * NS * QT + NS * 512];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kblk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
@@ -448,6 +497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(BwdParams p) {
   const bool causal = p.mask_kind & VY_MASK_CAUSAL;
   const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
   const bool key_dead = (kj >= p.S) || (haskp && !p.keypad[(int64_t)b * p.kp_sb + krow]);
+  const bool any_dead = __any(key_dead);
   const float c = p.scale * LOG2E;
 
   f32x16 dk[2], dv[2];
@@ -457,97 +507,136 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(BwdParams p) {
     for (int r = 0; r < 16; ++r) { dk[n][r] = 0.f; dv[n][r] = 0.f; }
 
   // query tiles that can see any key of this block: rows >= block_first_key - start_pos
-  const int nqt = (p.L + 31) / 32;
+  const int nqt = (p.L + QR - 1) / QR;
   int qt_first = 0;
   if (causal) {
     const int first_row = kblk * 128 - p.start_pos;
-    qt_first = first_row > 0 ? first_row / 32 : 0;
+    qt_first = first_row > 0 ? first_row / QR : 0;
   }
   const int per_head = nqt > qt_first ? nqt - qt_first : 0;
   const int total = per_head * n_rep;
 
-  // LDS-DMA: tile = 4 pieces of 1 KiB; wave w loads piece w of the Q tile and of the dO tile
-  const int ldP = wave * 1024 + lane * 16;
-  const int ld_row = ldP / RB, ld_off = ldP % RB;
-  const int ld_eoff = (((ld_off >> 4) ^ dual_sw(ld_row)) << 4) >> 1;
+  // LDS-DMA: tile = 8 pieces of 1 KiB; wave w loads pieces 2w, 2w+1 of the Q tile and of the dO tile
+  int ld_row[2], ld_eoff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int P = (wave * 2 + t) * 1024 + lane * 16;
+    const int row = P / RB, off = P % RB;
+    ld_row[t] = row;
+    ld_eoff[t] = (((off >> 4) ^ dual_sw(row)) << 4) >> 1;
+  }
+  const float* stat_src = (wave & 1) ? p.delta : p.lse;
   auto stage = [&](int it, int buf) {
     const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
     const int head = kvh * n_rep + hh;
-    int qr = qt * 32 + ld_row;
-    qr = qr < p.L ? qr : p.L - 1;
-    const bf16* qs = p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qr * p.q_sl + ld_eoff;
-    const bf16* gs = p.dout + (int64_t)b * p.o_sb + (int64_t)qr * p.o_sl + head * DH + ld_eoff;
-    __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)qs, (VY_LDS void*)(smem + buf * QT + wave * 1024), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)gs, (VY_LDS void*)(smem + (2 + buf) * QT + wave * 1024), 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int qr = qt * QR + ld_row[t];
+      qr = qr < p.L ? qr : p.L - 1;
+      const bf16* qs = p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qr * p.q_sl + ld_eoff[t];
+      const bf16* gs = p.dout + (int64_t)b * p.o_sb + (int64_t)qr * p.o_sl + head * DH + ld_eoff[t];
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)qs, (VY_LDS void*)(smem + buf * QT + (wave * 2 + t) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)gs, (VY_LDS void*)(smem + (NS + buf) * QT + (wave * 2 + t) * 1024), 16, 0, 0);
+    }
+    // row statistics: even waves bring lse, odd waves -delta (both pairs write the same bytes)
+    int sr = qt * QR + lane;
+    sr = sr < p.L ? sr : p.L - 1;
+    __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(stat_src + ((int64_t)b * p.h + head) * p.L + sr),
+                                     (VY_LDS void*)(smem + ST_OFF + buf * 512 + (wave & 1) * 256), 4, 0, 0);
   };
   const int r_sw = dual_sw(fr);
   const int li = lane & 15, g16 = (lane >> 4) & 1;
   const int t_row = 4 * fh + (li >> 2);
+  const int t_chunk = 2 * g16 + ((li & 3) >> 1), t_byte = 8 * (li & 1);
 
-  if (total > 0) {
-    stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-  }
-  for (int it = 0; it < total; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < total) stage(it + 1, buf ^ 1);
+  auto compute = [&](int it, int buf) {
     const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
-    const int head = kvh * n_rep + hh;
-    const int qbase = qt * 32;
-    // wave-uniform skip: every key of this wave is above the tile's last row's diagonal
-    if (!(causal && key0 > qbase + 31 + p.start_pos)) {
-      const char* qb_ = smem + buf * QT;
-      const char* gb_ = smem + (2 + buf) * QT;
-      // row constants: register r <-> query row qbase + (r&3) + 8(r>>2) + 4h
-      const float* lse = p.lse + ((int64_t)b * p.h + head) * p.L;
-      const float* dlt = p.delta + ((int64_t)b * p.h + head) * p.L;
-      f32x16 st, dp;
+    const char* qb_ = smem + buf * QT;
+    const char* gb_ = smem + (NS + buf) * QT;
+    const float* stl = reinterpret_cast<const float*>(smem + ST_OFF + buf * 512);
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
+    for (int blk = 0; blk < 2; ++blk) {
+      const int qbase = qt * QR + 32 * blk;
+      // wave-uniform skips: block beyond L, or every key of this wave above the block's last diagonal
+      if (qbase >= p.L || (causal && key0 > qbase + 31 + p.start_pos)) continue;
+      // register r <-> query row qbase + (r&3) + 8(r>>2) + 4fh: row constants straight from LDS
+      f32x16 st, dp, nl;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(stl + 32 * blk + 8 * rg + 4 * fh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(stl + 64 + 32 * blk + 8 * rg + 4 * fh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          int qi = qbase + 8 * rg + 4 * fh + e;
-          qi = qi < p.L ? qi : p.L - 1;
-          st[4 * rg + e] = -lse[qi] / p.scale;   // S' = S - lse/scale  ->  p = exp2(c * S')
-          dp[4 * rg + e] = -dlt[qi];
+          st[4 * rg + e] = 0.f;
+          nl[4 * rg + e] = l4[e] * -LOG2E;
+          dp[4 * rg + e] = d4[e];
         }
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qb_ + fr * RB + (((2 * ks + fh) ^ r_sw) << 4));
-        const bf16x8 ga = *reinterpret_cast<const bf16x8*>(gb_ + fr * RB + (((2 * ks + fh) ^ r_sw) << 4));
+        const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qb_ + (32 * blk + fr) * RB + (((2 * ks + fh) ^ r_sw) << 4));
+        const bf16x8 ga = *reinterpret_cast<const bf16x8*>(gb_ + (32 * blk + fr) * RB + (((2 * ks + fh) ^ r_sw) << 4));
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[ks], dp, 0, 0, 0);
       }
+      const bool need_mask = any_dead || qbase + 32 > p.L || (causal && key0 + 31 > qbase + p.start_pos);
       bf16x8 pf[2], dsf[2];
+      if (need_mask) {
+        // rows of this block the lane's key may see: [kj - start_pos - qbase, L - qbase)
+        unsigned rm = (unsigned)range_bits64(causal ? kj - p.start_pos - qbase : 0, min(32, p.L - qbase));
+        rm = key_dead ? 0u : rm >> (4 * fh);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = qbase + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        float pr = exp2f(st[r] * c);
-        if (key_dead || qi >= p.L || (causal && kj > qi + p.start_pos)) pr = 0.f;
-        pf[r >> 3][r & 7] = (bf16)pr;
-        dsf[r >> 3][r & 7] = (bf16)(pr * dp[r]);
+        for (int r = 0; r < 16; ++r) {
+          float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c, nl[r]));
+          pr = ((rm >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pr : 0.f;
+          pf[r >> 3][r & 7] = (bf16)pr;
+          dsf[r >> 3][r & 7] = (bf16)(pr * dp[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c, nl[r]));
+          pf[r >> 3][r & 7] = (bf16)pr;
+          dsf[r >> 3][r & 7] = (bf16)(pr * dp[r]);
+        }
       }
       // dV^T[d][key] += dO^T[d][q] . P[q][key];   dK^T[d][key] += Q^T[d][q] . dS[q][key]
+      auto frag = [&](const char* base, int f) {
+        const int n = f >> 1, row = 32 * blk + 16 * (f & 1) + t_row;
+        const int chunk = 4 * n + t_chunk;
+        return vy_lds_tr16_pair(base + row * RB + ((chunk ^ dual_sw(row)) << 4) + t_byte,
+                                base + (row + 8) * RB + ((chunk ^ dual_sw(row + 8)) << 4) + t_byte);
+      };
+      bf16x8 gfr[2], qfr[2];
+      gfr[0] = frag(gb_, 0);
+      qfr[0] = frag(qb_, 0);
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int row = 16 * s + t_row;
-          const int chunk = 4 * n + 2 * g16 + ((li & 3) >> 1);
-          const int o0 = row * RB + ((chunk ^ dual_sw(row)) << 4) + 8 * (li & 1);
-          const int o1 = (row + 8) * RB + ((chunk ^ dual_sw(row + 8)) << 4) + 8 * (li & 1);
-          union { struct { s16x4 a, b; } s_; bf16x8 v; } ug, uq;
-          ug.s_.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(gb_ + o0));
-          ug.s_.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(gb_ + o1));
-          uq.s_.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(qb_ + o0));
-          uq.s_.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((VY_LDS s16x4*)(qb_ + o1));
-          dv[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ug.v, pf[s], dv[n], 0, 0, 0);
-          dk[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uq.v, dsf[s], dk[n], 0, 0, 0);
+      for (int f = 0; f < 4; ++f) {
+        if (f + 1 < 4) {
+          gfr[(f + 1) & 1] = frag(gb_, f + 1);
+          qfr[(f + 1) & 1] = frag(qb_, f + 1);
+          vy_lgkm_wait<4>(gfr[f & 1], qfr[f & 1]);
+        } else {
+          vy_lgkm_wait<0>(gfr[f & 1], qfr[f & 1]);
         }
+        dv[f >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[f & 1], pf[f & 1], dv[f >> 1], 0, 0, 0);
+        dk[f >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[f & 1], dsf[f & 1], dk[f >> 1], 0, 0, 0);
+      }
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
+  };
+
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { vy_tie(kf[ks]); vy_tie(vf[ks]); }
+#pragma unroll
+  for (int s_ = 0; s_ < NS - 1; ++s_)
+    if (s_ < total) stage(s_, s_);
+  for (int it = 0; it < total; ++it) {
+    if (it + 1 < total) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (it + NS - 1 < total) stage(it + NS - 1, (it + NS - 1) % NS);
+    compute(it, it % NS);
   }
   if (kj < p.S) {
     bf16* DK = p.dk + (int64_t)b * p.dk_sb + (int64_t)kvh * p.dk_sh + (int64_t)kj * p.dk_sl;
@@ -632,6 +721,7 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   if (!q || !k || !v || !out || !dout || !lse || !delta_ws || !dq || !dk || !dv) VY_FAIL(VY_ERR_ARG, "%s: null tensor", who);
   if (B <= 0 || h <= 0 || hk <= 0 || h % hk || L <= 0 || S <= 0) VY_FAIL(VY_ERR_ARG, "%s: bad sizes", who);
   if ((mask_kind & VY_MASK_KEYPAD) && !keypad) VY_FAIL(VY_ERR_ARG, "%s: keypad mask requested but NULL", who);
+  if ((mask_kind & VY_MASK_KEYPAD) && S > 16384) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: key-padding masks cover at most 16384 keys", who);
   const int64_t s8[] = {q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, o_sb, o_sl,
                         dq_sb, dq_sh, dq_sl, dk_sb, dk_sh, dk_sl, dv_sb, dv_sh, dv_sl};
   for (int64_t x : s8)
