@@ -154,10 +154,12 @@ int vy_linear_dgrad(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, 
                     int64_t ldpre, int act, const void* add_to, int64_t ldadd, void* dx,
                     int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
 
-/* dW[N,K] (fp32, accumulate when beta != 0) = dY[M,N]^T . X[M,K];  db[N] (fp32) = colsum(dY). */
+/* dW[N,K] (fp32, accumulate when beta != 0) = alpha * dY[M,N]^T . X[M,K];  db[N] (fp32) likewise
+ * alpha * colsum(dY).  alpha_dev: optional DEVICE fp32 scalar (NULL = 1), e.g. the upstream
+ * gradient of a loss whose unit gradient is already stored in dY -- no host sync to read it. */
 int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
-                    int64_t lddw, float* db, float beta, int64_t M, int64_t N, int64_t K,
-                    int dtype, void* stream);
+                    int64_t lddw, float* db, float beta, const float* alpha_dev, int64_t M, int64_t N,
+                    int64_t K, int dtype, void* stream);
 
 /* LayerNorm backward: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;
  * dgamma/dbeta fp32 [N] accumulated (beta) from per-block partials in `ws`
@@ -207,6 +209,12 @@ int vy_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t i
                 float* loss_sum, float* count, int64_t M, int64_t V, int dtype, void* stream);
 int vy_xent_bwd(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, const float* lse,
                 const float* gscale, const float* count, int64_t M, int64_t V, int dtype, void* stream);
+/* Both in ONE pass over the logits (bf16, V <= 65536): `count` (device scalar: the number of rows
+ * with label != ignore) is an INPUT here; lse and loss_sum as in vy_xent_fwd, then the row is
+ * overwritten in place as in vy_xent_bwd.  The logits cross HBM once in each direction. */
+int vy_xent_fused(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, float* lse,
+                  float* loss_sum, const float* count, const float* gscale, int64_t M, int64_t V,
+                  int dtype, void* stream);
 
 /* out[c, r] = in[r, c] for a [R,C] matrix (bf16 or f32): keeps W^T copies for dgrad. */
 int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t R, int64_t C,

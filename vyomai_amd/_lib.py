@@ -34,7 +34,7 @@ PROTOTYPES = {
     "vy_gated_act_fwd": [_p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
     "vy_rope_fwd": [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i, _i64, _i, _i, _i, _p],
     "vy_linear_dgrad": [_p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i64, _i64, _i64, _i, _p],
-    "vy_linear_wgrad": [_p, _i64, _p, _i64, _p, _i64, _p, _f, _i64, _i64, _i64, _i, _p],
+    "vy_linear_wgrad": [_p, _i64, _p, _i64, _p, _i64, _p, _f, _p, _i64, _i64, _i64, _i, _p],
     "vy_layernorm_bwd": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _p, _f, _p, _i64, _i64, _i, _p],
     "vy_attn_bwd": [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,
                     _p, _p, _i64, _i64, _p, _p,
@@ -44,6 +44,7 @@ PROTOTYPES = {
     "vy_act_bwd": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
     "vy_xent_fwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
     "vy_xent_bwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
+    "vy_xent_fused": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _p],
     "vy_transpose": [_p, _i64, _p, _i64, _i64, _i64, _i, _p],
     "vy_decoder_step": [_p, _p, _i64, _p, _p, _p, _i64, _p],
     "vy_cast": [_p, _p, _i64, _i, _i, _p],

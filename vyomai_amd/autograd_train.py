@@ -37,9 +37,12 @@ def _wt(param: torch.Tensor, dtype) -> torch.Tensor:
     if cache is None or cache[0] != key or cache[1].dtype != dtype:
         N, K = src.shape
         ld = (N + 7) // 8 * 8
-        buf = torch.zeros((K, ld), dtype=dtype, device=src.device)
-        ops.transpose(src, buf[:, :N])
-        cache = (key, buf[:, :N])
+        if cache is not None and cache[1].dtype == dtype and cache[1].device == src.device:
+            view = cache[1]  # same buffer: the pad columns were zeroed once and are never written
+        else:
+            view = torch.zeros((K, ld), dtype=dtype, device=src.device)[:, :N]
+        ops.transpose(src, view)
+        cache = (key, view)
         param._vy_wt = cache
     return cache[1]
 
@@ -56,15 +59,15 @@ def _notify(*params) -> None:
                 cb(p)
 
 
-def _wgrad(dy, x, w: torch.Tensor, b: Optional[torch.Tensor]):
+def _wgrad(dy, x, w: torch.Tensor, b: Optional[torch.Tensor], alpha: Optional[torch.Tensor] = None):
     """-> (dw, db) to return to autograd (None when accumulated in place)."""
     if _direct(w) and (b is None or _direct(b)):
-        ops.linear_wgrad(dy, x, w.grad, None if b is None else b.grad, accumulate=True)
+        ops.linear_wgrad(dy, x, w.grad, None if b is None else b.grad, accumulate=True, alpha=alpha)
         _notify(w, b)
         return None, None
     dw = torch.empty(w.shape, dtype=torch.float32, device=w.device)
     db = torch.empty(b.shape, dtype=torch.float32, device=w.device) if b is not None else None
-    ops.linear_wgrad(dy, x, dw, db, accumulate=False)
+    ops.linear_wgrad(dy, x, dw, db, accumulate=False, alpha=alpha)
     return dw.to(w.dtype), (db.to(b.dtype) if b is not None else None)
 
 
@@ -305,9 +308,10 @@ def _gelu_bwd(dy, pre):
 class LMHeadLossFn(torch.autograd.Function):
     """Shifted causal-LM loss fused with the LM head: mean cross-entropy of logits[:, :-1] against
     labels[:, 1:] with ignore_index (Examples/vyom-ai-decoder_clm.ipynb cell 29).  The logits
-    ([M, V] bf16, padded row stride) are produced by the vocabulary GEMM, reduced by vy_xent_fwd
-    and overwritten IN PLACE by their gradient in backward (vy_xent_bwd) -- they are never copied,
-    up-cast or re-materialised."""
+    ([M, V] bf16, padded row stride) are produced by the vocabulary GEMM, then reduced AND
+    overwritten IN PLACE by their unit gradient in one pass (vy_xent_fused; vy_xent_fwd + vy_xent_bwd
+    beyond 65536 columns) -- they are never copied, up-cast or re-materialised (SURVEY.md section 8f
+    item 1).  Backward multiplies by the upstream gradient through the GEMMs (a device scalar)."""
 
     @staticmethod
     def forward(ctx, hidden, labels, ignore_index, wd, bd, ln_w, ln_b, wv, bias, eps):
@@ -330,10 +334,18 @@ class LMHeadLossFn(torch.autograd.Function):
         shifted = shifted.view(-1)
         lse = torch.empty(B * L, dtype=torch.float32, device=dev)
         acc = torch.zeros(2, dtype=torch.float32, device=dev)  # [loss_sum, count]
-        ops.xent_fwd(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2])
+        fused = V <= 65536
+        if fused:
+            # one pass: loss AND the unit gradient (d loss / d logits for an upstream gradient of 1),
+            # written over the logits; backward scales by the actual upstream gradient (linearity)
+            acc[1] = (shifted != ignore_index).sum()
+            ops.xent_fused_(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2], _one(dev))
+        else:
+            ops.xent_fwd(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2])
         ctx.save_for_backward(hidden, pre, g, n, mean, rstd, buf, shifted, lse, acc)
         ctx.params = (wd, bd, ln_w, ln_b, wv, bias)
         ctx.ignore = ignore_index
+        ctx.fused = fused
         return acc[0] / acc[1].clamp_min(1.0)
 
     @staticmethod
@@ -344,15 +356,31 @@ class LMHeadLossFn(torch.autograd.Function):
         V = wv.shape[0]
         logits = buf[:, :V]
         gs = gout.detach().to(torch.float32).reshape(1).contiguous()
-        ops.xent_bwd_(logits, shifted, ctx.ignore, lse, gs, acc[1:2])   # logits <- dlogits
+        alpha = None
+        if ctx.fused:
+            alpha = gs          # logits already hold the unit gradient
+        else:
+            ops.xent_bwd_(logits, shifted, ctx.ignore, lse, gs, acc[1:2])   # logits <- dlogits
         # contract over the padded vocabulary width (pad columns of both operands are zero)
         dn = ops.linear_dgrad(buf, _wt_padded(wv, dt, buf.shape[1]))
-        dwv, dbias = _wgrad(logits, n.view(buf.shape[0], -1), wv, bias)
+        if alpha is not None:
+            dn = dn * alpha.to(dt)
+        dwv, dbias = _wgrad(logits, n.view(buf.shape[0], -1), wv, bias, alpha=alpha)
         dg, dgam, dbet = _ln_bwd(dn.view(g.shape), g, ln_w, ln_b, mean, rstd)
         dpre = _gelu_bwd(dg, pre)
         dh = ops.linear_dgrad(dpre, _wt(wd, dt))
         dwd, dbd = _wgrad(dpre, hidden, wd, bd)
         return dh, None, None, dwd, dbd, dgam, dbet, dwv, dbias, None
+
+
+_ONES = {}
+
+
+def _one(dev) -> torch.Tensor:
+    t = _ONES.get(dev)
+    if t is None:
+        t = _ONES[dev] = torch.ones(1, dtype=torch.float32, device=dev)
+    return t
 
 
 def _wt_padded(param, dtype, ld):

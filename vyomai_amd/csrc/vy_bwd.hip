@@ -46,8 +46,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
 template <int BN>
 __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
-    float* __restrict__ dW, int64_t lddw, float* __restrict__ db, int M, int N, int K, int tiles_k,
-    int tiles_nk, int m_chunk, int diag) {
+    float* __restrict__ dW, int64_t lddw, float* __restrict__ db, const float* __restrict__ alpha_dev,
+    int M, int N, int K, int tiles_k, int tiles_nk, int m_chunk, int diag) {
   constexpr int NW = BN / 32;                 // waves: (BN/64) x 2
   constexpr int AROW = BN * 2, BROW = 256;    // LDS row bytes of the dY and X tiles
   constexpr int ATILE = 64 * AROW, BTILE = 64 * BROW;
@@ -179,10 +179,11 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
     if (acc[0][0][0] == 12345.678f) dW[0] = 1.f;
     return;
   }
+  const float alpha = alpha_dev ? *alpha_dev : 1.0f;
   if (do_db) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const float t_ = sdb[i] + __shfl_xor(sdb[i], 32, 64);
+      const float t_ = (sdb[i] + __shfl_xor(sdb[i], 32, 64)) * alpha;
       const int n = n0 + wn * 64 + 32 * i + fr;
       if (fh == 0 && n < N) atomicAdd(db + n, t_);
     }
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        if (n < N) atomicAdd(dW + (int64_t)n * lddw + k, acc[i][j][r]);
+        if (n < N) atomicAdd(dW + (int64_t)n * lddw + k, acc[i][j][r] * alpha);
       }
     }
 }
@@ -664,8 +665,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(BwdParams p) {
 }  // namespace
 
 extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
-                               int64_t lddw, float* db, float beta, int64_t M, int64_t N, int64_t K,
-                               int dtype, void* stream) {
+                               int64_t lddw, float* db, float beta, const float* alpha_dev, int64_t M,
+                               int64_t N, int64_t K, int dtype, void* stream) {
   const char* who = "vy_linear_wgrad";
   if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only (fp32 is the inference parity path)", who);
   if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0) VY_FAIL(VY_ERR_ARG, "%s: bad arguments", who);
@@ -697,10 +698,10 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   splits = vy_cdiv(M, m_chunk);
   if (big)
     hipLaunchKernelGGL(wgrad_tn_bf16_kernel<256>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, (const bf16*)dy,
-                       lddy, (const bf16*)x, ldx, dw, lddw, db, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
+                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
   else
     hipLaunchKernelGGL(wgrad_tn_bf16_kernel<128>, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
-                       lddy, (const bf16*)x, ldx, dw, lddw, db, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
+                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
   VY_CHECK_LAUNCH(who);
   return VY_OK;
 }

@@ -860,6 +860,17 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
       const int tn2 = (int)vy_cdiv(N, 256);
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq);
+    } else if (var == 10) {  // 4 waves, 128 x 128 per wave: fewest LDS bytes per FLOP
+      const int tn2 = (int)vy_cdiv(N, 256);
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(256), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq);
+    } else if (var == 12) {  // 128 x 192, 4 waves, 80 KiB LDS: two workgroups per CU overlap epilogue and main loop
+      const int tm2 = (int)vy_cdiv(M, 128);
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm2 * tn), dim3(256), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    } else if (var == 11) {  // 4 waves, 128 x 96 per wave
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
     } else if (var == 9 || var < 0) {
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);

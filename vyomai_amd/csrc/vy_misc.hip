@@ -13,7 +13,7 @@ void vy_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vy_last_error(void) { return g_err; }
-extern "C" int vy_abi_version(void) { return 1; }
+extern "C" int vy_abi_version(void) { return 2; }
 
 namespace {
 
@@ -511,6 +511,81 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(T* __restrict__ logits, i
   }
 }
 
+// Fused forward + backward: the row (<= 65536 bf16 logits) lives in the registers of a 1024-thread
+// workgroup between the two reductions and the gradient store, so the logits cross HBM exactly
+// twice (one read, one write) instead of three reads and one write for vy_xent_fwd + vy_xent_bwd.
+__global__ __launch_bounds__(1024) void xent_fused_kernel(bf16* __restrict__ logits, int64_t ld,
+                                                          const int64_t* __restrict__ labels, int64_t ignore,
+                                                          float* __restrict__ lse, float* __restrict__ loss_sum,
+                                                          const float* __restrict__ count,
+                                                          const float* __restrict__ gscale, int V) {
+  constexpr int CPT = 8;  // 16-byte chunks per thread
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  const int64_t m = blockIdx.x;
+  const int64_t label = labels[m];
+  bf16* row = logits + m * ld;
+  const int nch = (V + 7) / 8;
+  bf16x8 zero8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero8[e] = (bf16)0.f;
+  if (label == ignore) {
+    for (int c = tid; c < nch; c += 1024) *reinterpret_cast<bf16x8*>(row + (int64_t)c * 8) = zero8;
+    if (tid == 0) lse[m] = 0.f;
+    return;
+  }
+  const float x_label = (float)row[label];  // read before any thread overwrites the row (barriers below)
+  bf16x8 v[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + i * 1024;
+    if (c < nch) v[i] = *reinterpret_cast<const bf16x8*>(row + (int64_t)c * 8);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + i * 1024;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c * 8 + e < V) mx = fmaxf(mx, (float)v[i][e]);
+    }
+  }
+  const float gmx = block_reduce(mx, red, true);
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + i * 1024;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (c * 8 + e < V) sm += __expf((float)v[i][e] - gmx);
+    }
+  }
+  const float gsm = block_reduce(sm, red, false);
+  const float l = gmx + __logf(gsm);
+  if (tid == 0) {
+    lse[m] = l;
+    atomicAdd(loss_sum, l - x_label);
+  }
+  const float sc = (*gscale) / fmaxf(*count, 1.0f);
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + i * 1024;
+    if (c < nch) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int col = c * 8 + e;
+        float g = 0.f;  // pad columns stay zero
+        if (col < V) g = (__expf((float)v[i][e] - l) - (col == label ? 1.f : 0.f)) * sc;
+        o[e] = (bf16)g;
+      }
+      *reinterpret_cast<bf16x8*>(row + (int64_t)c * 8) = o;
+    }
+  }
+}
+
 template <typename T>
 int ln_fwd_dispatch(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y, int64_t ldy,
                     float* mean, float* rstd, int64_t M, int64_t N, float eps, hipStream_t st) {
@@ -699,6 +774,19 @@ extern "C" int vy_xent_bwd(void* logits, int64_t ld, const int64_t* labels, int6
   else if (dtype == VY_F32) hipLaunchKernelGGL(xent_bwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (float*)logits, ld, labels, ignore_index, lse, gscale, count, (int)V);
   else VY_FAIL(VY_ERR_ARG, "vy_xent_bwd: bad dtype %d", dtype);
   VY_CHECK_LAUNCH("vy_xent_bwd");
+  return VY_OK;
+}
+
+extern "C" int vy_xent_fused(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, float* lse,
+                             float* loss_sum, const float* count, const float* gscale, int64_t M, int64_t V,
+                             int dtype, void* stream) {
+  if (!logits || !labels || !lse || !loss_sum || !count || !gscale || M <= 0 || V <= 0) VY_FAIL(VY_ERR_ARG, "vy_xent_fused: bad arguments");
+  if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_xent_fused: bf16 only (use vy_xent_fwd + vy_xent_bwd)");
+  if (V > 65536) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_xent_fused: V=%ld exceeds the 65536 columns a workgroup keeps in registers (use vy_xent_fwd + vy_xent_bwd)", (long)V);
+  if (ld % 8 || ld < vy_cdiv(V, 8) * 8 || (uintptr_t)logits % 16) VY_FAIL(VY_ERR_ARG, "vy_xent_fused: rows must be 16-byte aligned and cover the padded width");
+  hipLaunchKernelGGL(xent_fused_kernel, dim3((unsigned)M), dim3(1024), 0, (hipStream_t)stream, (bf16*)logits, ld, labels,
+                     ignore_index, lse, loss_sum, count, gscale, (int)V);
+  VY_CHECK_LAUNCH("vy_xent_fused");
   return VY_OK;
 }
 

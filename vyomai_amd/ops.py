@@ -200,15 +200,18 @@ def linear_dgrad(dy: Tensor, wt: Tensor, pre: Optional[Tensor] = None, act: int 
     return out
 
 
-def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], accumulate: bool) -> None:
-    """dw (fp32 [N,K]) (+)= dy^T @ x ; db (fp32 [N]) (+)= colsum(dy).  (vy_linear_wgrad)"""
-    _need_gpu(dy, x, dw, db)
+def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], accumulate: bool,
+                 alpha: Optional[Tensor] = None) -> None:
+    """dw (fp32 [N,K]) (+)= alpha * dy^T @ x ; db (fp32 [N]) (+)= alpha * colsum(dy).  (vy_linear_wgrad)
+    alpha: optional fp32 device scalar (read by the kernel, no host sync)."""
+    _need_gpu(dy, x, dw, db, alpha)
+    assert alpha is None or (alpha.dtype == torch.float32 and alpha.numel() == 1)
     d2, x2 = _rows(dy), _rows(x)
     M, N = d2.shape
     K = x2.shape[1]
     assert dw.dtype == torch.float32 and dw.shape == (N, K) and dw.stride(1) == 1
     call("vy_linear_wgrad", d2.data_ptr(), d2.stride(0), x2.data_ptr(), x2.stride(0), dw.data_ptr(),
-         dw.stride(0), _ptr(db), 1.0 if accumulate else 0.0, M, N, K, dtype_code(dy.dtype), _stream())
+         dw.stride(0), _ptr(db), 1.0 if accumulate else 0.0, _ptr(alpha), M, N, K, dtype_code(dy.dtype), _stream())
 
 
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor,
@@ -297,6 +300,16 @@ def xent_bwd_(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, 
     M, V = logits2d.shape
     call("vy_xent_bwd", logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), ignore_index, lse.data_ptr(),
          gscale.data_ptr(), count.data_ptr(), M, V, dtype_code(logits2d.dtype), _stream())
+
+
+def xent_fused_(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, loss_sum: Tensor,
+                count: Tensor, gscale: Tensor) -> None:
+    """One pass: lse / loss_sum as xent_fwd, then logits <- d loss / d logits in place (vy_xent_fused).
+    count (#rows with label != ignore) is an input here."""
+    _need_gpu(logits2d, labels, lse, loss_sum, count, gscale)
+    M, V = logits2d.shape
+    call("vy_xent_fused", logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), ignore_index, lse.data_ptr(),
+         loss_sum.data_ptr(), count.data_ptr(), gscale.data_ptr(), M, V, dtype_code(logits2d.dtype), _stream())
 
 
 def rmsnorm(x: Tensor, w: Tensor, eps: float, w_offset: float = 1.0) -> Tensor:
