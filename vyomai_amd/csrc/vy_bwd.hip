@@ -43,7 +43,11 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
 // tile 128(n) x 128(k), 64 rows of m per stage, 4 waves 2x2 of 64x64, split over M
 // ------------------------------------------------------------------------------------------
 // tile BN(n) x 128(k), 64 rows of m per stage; BN/64 x 2 waves of 64x64
-template <int BN>
+// NS stages of LDS: the loads of the next NS-1 stages are in flight while a stage is multiplied; a
+// stage is waited for with a COUNTED vmcnt (its PA+PB LDS-DMA instructions are the wave's oldest)
+// and one raw s_barrier -- inside a training step the operands come from HBM, not from a warm L2,
+// and a 2-stage loop that drains vmcnt(0) every 64 rows pays that latency once per stage.
+template <int BN, int NS>
 __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
     float* __restrict__ dW, int64_t lddw, float* __restrict__ db, const float* __restrict__ alpha_dev,
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
   constexpr int ATILE = 64 * AROW, BTILE = 64 * BROW;
   constexpr int STAGE = ATILE + BTILE;
   constexpr int PA = ATILE / 1024 / NW, PB = BTILE / 1024 / NW;  // LDS-DMA pieces per wave
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
@@ -123,12 +127,18 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
   const int a_rd = (2 * (wn * 64 + 16 * g16 + 4 * (li & 3)));  // + 64*i, then ^ tr_sw
   const int b_rd = (2 * (wk * 64 + 16 * g16 + 4 * (li & 3)));
 
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
+#pragma unroll
+  for (int s_ = 0; s_ < NS - 1; ++s_)
+    if (s_ < nst) stage(s_, s_);
   for (int s = 0; s < nst; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nst) stage(s + 1, cur ^ 1);
+    const int cur = s % NS;
+    const int younger = min(NS - 2, nst - 1 - s);  // stages issued after stage s
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PA + PB)) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + NS - 1 < nst) stage(s + NS - 1, (s + NS - 1) % NS);  // the buffer stage s-1 was read from
     const char* ab = smem + cur * STAGE;
     const char* bb = ab + ATILE;
     // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (asm reads + counted
@@ -171,8 +181,6 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
         }
       }
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
   }
   const int fr = lane & 31;
   if (diag == 1) {  // timing-only: no atomic epilogue (results wrong)
@@ -681,12 +689,14 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
     if (db && hipMemsetAsync(db, 0, N * sizeof(float), st) != hipSuccess)
       VY_FAIL(VY_ERR_LAUNCH, "%s: memset failed", who);
   }
-  // tile 256(n) x 128(k) (8 waves, 11.7 B/kFLOP of L2 traffic) when it still yields enough
-  // (tile, m-split) work items without excessive atomic traffic; else 128 x 128 (4 waves)
+  // tile 128(n) x 128(k), 4 waves, 2 stages = 64 KiB of LDS: TWO workgroups per CU, which hides the
+  // load latency better than one 256 x 128 workgroup (8 waves, 96 KiB) or a deeper ring with one
+  // workgroup per CU -- measured inside the training step: 256-wide 142/165 us vs 96/125 us (QKV /
+  // FFN1), 3- and 4-stage rings +45 %.  VY_WGRAD_VARIANT=1 / VY_WGRAD_STAGES keep them selectable.
   static const int wv = [] { const char* e = getenv("VY_WGRAD_VARIANT"); return e ? atoi(e) : -1; }();
   static const int diag = [] { const char* e = getenv("VY_WGRAD_DIAG"); return e ? atoi(e) : 0; }();
   static const int tgt = [] { const char* e = getenv("VY_WGRAD_TARGET"); return e ? atoi(e) : 0; }();
-  const bool big = wv == 1 || (wv < 0 && N >= 2048);
+  const bool big = wv == 1;  // 256-wide tiles measured slower at every training shape (1 workgroup per CU)
   const int BNt = big ? 256 : 128;
   const int tiles_n = (int)vy_cdiv(N, BNt), tiles_k = (int)vy_cdiv(K, 128);
   const int tiles = tiles_n * tiles_k;
@@ -696,11 +706,21 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   if (splits < 1) splits = 1;
   int64_t m_chunk = vy_cdiv(vy_cdiv(M, splits), 64) * 64;
   splits = vy_cdiv(M, m_chunk);
-  if (big)
-    hipLaunchKernelGGL(wgrad_tn_bf16_kernel<256>, dim3((unsigned)(tiles * splits)), dim3(512), 0, st, (const bf16*)dy,
+  static const int ns = [] { const char* e = getenv("VY_WGRAD_STAGES"); return e ? atoi(e) : 2; }();
+  if (big && ns == 2)
+    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<256, 2>), dim3((unsigned)(tiles * splits)), dim3(512), 0, st, (const bf16*)dy,
+                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
+  else if (big)
+    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<256, 3>), dim3((unsigned)(tiles * splits)), dim3(512), 0, st, (const bf16*)dy,
+                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
+  else if (ns == 2)
+    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<128, 2>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
+                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
+  else if (ns == 4)
+    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<128, 4>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
                        lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
   else
-    hipLaunchKernelGGL(wgrad_tn_bf16_kernel<128>, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
+    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<128, 3>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
                        lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
   VY_CHECK_LAUNCH(who);
   return VY_OK;
