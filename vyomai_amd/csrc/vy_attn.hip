@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   const int v_sw = (RB == 128) ? (((li >> 3) & 1) << 6) : (((li >> 2) & 3) << 6);
   const int v_lane_row = 4 * fh + (li >> 2);            // + 32kb + 16s + 8u
   const int v_lane_off = 32 * g16 + 8 * (li & 3);       // + 64n, then ^ v_sw
+  unsigned v_lds[ND];  // LDS byte address of V^T fragment column n, row v_lane_row, buffer 0 of the K ring
+#pragma unroll
+  for (int n = 0; n < ND; ++n) v_lds[n] = vy_lds_addr(smem) + v_lane_row * RB + ((64 * n + v_lane_off) ^ v_sw);
 
   f32x16 o[ND];
 #pragma unroll
@@ -240,24 +243,29 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[kb][s][j] = (bf16)st[kb][8 * s + j];
-    // V^T fragments: asm transposing reads (see vy_common.h), one fragment ahead of its MFMA
-    auto vfrag = [&](int f) {
-      const int n = f >> 2, kb = (f >> 1) & 1, s = f & 1;
-      const char* a_ = vb_ + (32 * kb + 16 * s + v_lane_row) * RB + ((64 * n + v_lane_off) ^ v_sw);
-      return vy_lds_tr16_pair(a_, a_ + 8 * RB);
+    // V^T fragments: asm transposing reads (see vy_common.h), one fragment ahead of its MFMA.  One
+    // base address per 32-wide d block; key block, k-step and the +8 row go into the offset field.
+    unsigned vbase[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) vbase[n] = v_lds[n] + buf * TILE;
+    auto vfrag = [&](auto f_c) {
+      constexpr int f = decltype(f_c)::value;
+      constexpr int n = f >> 2, kb = (f >> 1) & 1, s = f & 1;
+      return vy_lds_tr16_pair_off<NS * TILE + (32 * kb + 16 * s) * RB, NS * TILE + (32 * kb + 16 * s + 8) * RB>(vbase[n]);
     };
     bf16x8 vfr[2];
-    vfr[0] = vfrag(0);
-#pragma unroll
-    for (int f = 0; f < 4 * ND; ++f) {
-      if (f + 1 < 4 * ND) {
-        vfr[(f + 1) & 1] = vfrag(f + 1);
+    vfr[0] = vfrag(std::integral_constant<int, 0>{});
+    auto pv = [&](auto f_c) {
+      constexpr int f = decltype(f_c)::value;
+      if constexpr (f + 1 < 4 * ND) {
+        vfr[(f + 1) & 1] = vfrag(std::integral_constant<int, f + 1>{});
         vy_lgkm_wait<2>(vfr[f & 1]);
       } else {
         vy_lgkm_wait<0>(vfr[f & 1]);
       }
       o[f >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[f & 1], pf[(f >> 1) & 1][f & 1], o[f >> 2], 0, 0, 0);
-    }
+    };
+    vy_static_for<4 * ND>(pv);
   };
 
   // Loads run NS-1 tiles ahead of the MFMAs: a tile is waited for with a COUNTED vmcnt (its own

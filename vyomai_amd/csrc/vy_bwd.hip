@@ -42,21 +42,23 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
 // wgrad: dW[n,k] += sum_m dY[m,n] X[m,k]
 // tile 128(n) x 128(k), 64 rows of m per stage, 4 waves 2x2 of 64x64, split over M
 // ------------------------------------------------------------------------------------------
-// tile BN(n) x 128(k), 64 rows of m per stage; BN/64 x 2 waves of 64x64
+// tile BN(n) x BKW(k), MS rows of m per stage; (BN/64) x 2 waves, each 64(n) x BKW/2(k)
 // NS stages of LDS: the loads of the next NS-1 stages are in flight while a stage is multiplied; a
 // stage is waited for with a COUNTED vmcnt (its PA+PB LDS-DMA instructions are the wave's oldest)
-// and one raw s_barrier -- inside a training step the operands come from HBM, not from a warm L2,
-// and a 2-stage loop that drains vmcnt(0) every 64 rows pays that latency once per stage.
-template <int BN, int NS>
-__global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
+// and one raw s_barrier.
+template <int BN, int BKW, int MS, int NS>
+__global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kernel(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
     float* __restrict__ dW, int64_t lddw, float* __restrict__ db, const float* __restrict__ alpha_dev,
     int M, int N, int K, int tiles_k, int tiles_nk, int m_chunk, int diag) {
   constexpr int NW = BN / 32;                 // waves: (BN/64) x 2
-  constexpr int AROW = BN * 2, BROW = 256;    // LDS row bytes of the dY and X tiles
-  constexpr int ATILE = 64 * AROW, BTILE = 64 * BROW;
+  constexpr int WKT = BKW / 2, TJ = WKT / 32; // k extent of a wave, 32-wide fragments along k
+  constexpr int AROW = BN * 2, BROW = BKW * 2;  // LDS row bytes of the dY and X tiles
+  constexpr int ATILE = MS * AROW, BTILE = MS * BROW;
   constexpr int STAGE = ATILE + BTILE;
   constexpr int PA = ATILE / 1024 / NW, PB = BTILE / 1024 / NW;  // LDS-DMA pieces per wave
+  constexpr int KS = MS / 16;
+  static_assert(PA * 1024 * NW == ATILE && PB * 1024 * NW == BTILE && (KS == 2 || KS == 4), "tile / wave layout mismatch");
   __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,11 +66,11 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int split = wg / tiles_nk, t2 = wg - split * tiles_nk;
   const int tile_n = t2 / tiles_k, tile_k = t2 - tile_n * tiles_k;
-  const int n0 = tile_n * BN, k0 = tile_k * 128;
+  const int n0 = tile_n * BN, k0 = tile_k * BKW;
   const int m_begin = split * m_chunk;
   const int m_end = min(M, m_begin + m_chunk);
   if (m_begin >= m_end) return;
-  const int nst = (m_end - m_begin + 63) / 64;
+  const int nst = (m_end - m_begin + MS - 1) / MS;
 
   // LDS-DMA geometry: 1-KiB pieces; 64-byte swizzle (row & 3) << 6 on the source side
   int a_row[PA], a_off[PA], b_row[PB], b_off[PB];
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
   }
   const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
   auto stage = [&](int s, int buf) {
-    const int mb = m_begin + s * 64;
+    const int mb = m_begin + s * MS;
 #pragma unroll
     for (int t = 0; t < PA; ++t) {
       const int m = mb + a_row[t];
@@ -105,11 +107,11 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -125,7 +127,12 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
   const int tr_row = 4 * fh + (li >> 2);                  // + 16*s (second read +8)
   const int tr_sw = ((li >> 2) & 3) << 6;                 // (row & 3) << 6
   const int a_rd = (2 * (wn * 64 + 16 * g16 + 4 * (li & 3)));  // + 64*i, then ^ tr_sw
-  const int b_rd = (2 * (wk * 64 + 16 * g16 + 4 * (li & 3)));
+  const int b_rd = (2 * (wk * WKT + 16 * g16 + 4 * (li & 3)));
+  unsigned a_lds[2], b_lds[TJ];   // LDS byte address of fragment column i / j, row tr_row, stage 0
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a_lds[i] = vy_lds_addr(smem) + tr_row * AROW + ((a_rd + 64 * i) ^ tr_sw);
+#pragma unroll
+  for (int j = 0; j < TJ; ++j) b_lds[j] = vy_lds_addr(smem) + tr_row * BROW + ((b_rd + 64 * j) ^ tr_sw);
 
 #pragma unroll
   for (int s_ = 0; s_ < NS - 1; ++s_)
@@ -139,37 +146,42 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (s + NS - 1 < nst) stage(s + NS - 1, (s + NS - 1) % NS);  // the buffer stage s-1 was read from
-    const char* ab = smem + cur * STAGE;
-    const char* bb = ab + ATILE;
     // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (asm reads + counted
-    // lgkmcnt: see vy_common.h -- the builtin form would drain the LDS-DMA prefetch first)
-    bf16x8 af[2][2], bfr[2][2];
-    auto frags = [&](int ks, bf16x8* a_, bf16x8* b_) {
+    // lgkmcnt: see vy_common.h -- the builtin form would drain the LDS-DMA prefetch first).  One
+    // base address per fragment column; the k-step and the +8 row go into the offset field.
+    unsigned a_base[2], b_base[TJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const char* q_ = ab + (16 * ks + tr_row) * AROW + ((a_rd + 64 * i) ^ tr_sw);
-        a_[i] = vy_lds_tr16_pair(q_, q_ + 8 * AROW);
-      }
+    for (int i = 0; i < 2; ++i) a_base[i] = a_lds[i] + cur * STAGE;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const char* q_ = bb + (16 * ks + tr_row) * BROW + ((b_rd + 64 * j) ^ tr_sw);
-        b_[j] = vy_lds_tr16_pair(q_, q_ + 8 * BROW);
-      }
+    for (int j = 0; j < TJ; ++j) b_base[j] = b_lds[j] + cur * STAGE;
+    bf16x8 af[2][2], bfr[2][TJ];
+    auto frags = [&](auto ks_c, bf16x8* a_, bf16x8* b_) {
+      constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a_[i] = vy_lds_tr16_pair_off<16 * ks * AROW, (16 * ks + 8) * AROW>(a_base[i]);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+        b_[j] = vy_lds_tr16_pair_off<ATILE + 16 * ks * BROW, ATILE + (16 * ks + 8) * BROW>(b_base[j]);
     };
-    frags(0, af[0], bfr[0]);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int c_ = ks & 1;
-      if (ks < 3) {
-        frags(ks + 1, af[c_ ^ 1], bfr[c_ ^ 1]);
-        vy_lgkm_wait<8>(af[c_][0], af[c_][1], bfr[c_][0], bfr[c_][1]);
+    frags(std::integral_constant<int, 0>{}, af[0], bfr[0]);
+    auto kstep = [&](auto ks_c) {
+      constexpr int ks = decltype(ks_c)::value;
+      constexpr int c_ = ks & 1;
+      if constexpr (ks < KS - 1) {
+        frags(std::integral_constant<int, ks + 1>{}, af[c_ ^ 1], bfr[c_ ^ 1]);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (2 + TJ)) : "memory");
       } else {
-        vy_lgkm_wait<0>(af[c_][0], af[c_][1], bfr[c_][0], bfr[c_][1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) vy_tie(af[c_][i]);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) vy_tie(bfr[c_][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c_][i], bfr[c_][j], acc[i][j], 0, 0, 0);
       if (do_db) {
 #pragma unroll
@@ -180,7 +192,8 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
           for (int e = 0; e < 4; ++e) sdb[i] = __builtin_amdgcn_fdot2_f32_bf16(u_.h[e], ones2, sdb[i], false);
         }
       }
-    }
+    };
+    vy_static_for<KS>(kstep);
   }
   const int fr = lane & 31;
   if (diag == 1) {  // timing-only: no atomic epilogue (results wrong)
@@ -199,8 +212,8 @@ __global__ __launch_bounds__(BN * 2) void wgrad_tn_bf16_kernel(
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = k0 + wk * 64 + 32 * j + fr;
+    for (int j = 0; j < TJ; ++j) {
+      const int k = k0 + wk * WKT + 32 * j + fr;
       if (k >= K) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -356,6 +369,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdParams p) {
   const int li = lane & 15, g16 = (lane >> 4) & 1;
   const int t_row = 4 * fh + (li >> 2);
   const int t_chunk = 2 * g16 + ((li & 3) >> 1), t_byte = 8 * (li & 1);
+  unsigned k_lds[2][2];  // K^T fragment of d block n, rows t_row (+8), K ring buffer 0
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = t_row + 8 * u;
+      k_lds[n][u] = vy_lds_addr(smem) + row * RB + (((4 * n + t_chunk) ^ dual_sw(row)) << 4) + t_byte;
+    }
 
   f32x16 dq[2];
 #pragma unroll
@@ -423,25 +444,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdParams p) {
           ds[kb][r >> 3][r & 7] = (bf16)(pr * dp[kb][r]);
         }
     }
-    // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]; K^T fragments by asm transposing reads, one ahead
-    auto kfrag = [&](int f) {
-      const int n = f >> 2, row = 32 * ((f >> 1) & 1) + 16 * (f & 1) + t_row;
-      const int chunk = 4 * n + t_chunk;
-      return vy_lds_tr16_pair(kb_ + row * RB + ((chunk ^ dual_sw(row)) << 4) + t_byte,
-                              kb_ + (row + 8) * RB + ((chunk ^ dual_sw(row + 8)) << 4) + t_byte);
+    // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]; K^T fragments by asm transposing reads, one ahead.
+    // Base addresses per (d block, row / row+8); key block and k-step go into the offset field.
+    unsigned kbase[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) kbase[n][u] = k_lds[n][u] + buf * TILE;
+    auto kfrag = [&](auto f_c) {
+      constexpr int f = decltype(f_c)::value;
+      constexpr int n = f >> 2, ro = (32 * ((f >> 1) & 1) + 16 * (f & 1)) * RB;
+      union { struct { s16x4 a, b; } s_; bf16x8 v; } u;
+      u.s_.a = vy_lds_tr16_off<ro>(kbase[n][0]);
+      u.s_.b = vy_lds_tr16_off<ro>(kbase[n][1]);
+      return u.v;
     };
     bf16x8 kfr[2];
-    kfr[0] = kfrag(0);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {
-      if (f + 1 < 8) {
-        kfr[(f + 1) & 1] = kfrag(f + 1);
+    kfr[0] = kfrag(std::integral_constant<int, 0>{});
+    auto step = [&](auto f_c) {
+      constexpr int f = decltype(f_c)::value;
+      if constexpr (f + 1 < 8) {
+        kfr[(f + 1) & 1] = kfrag(std::integral_constant<int, f + 1>{});
         vy_lgkm_wait<2>(kfr[f & 1]);
       } else {
         vy_lgkm_wait<0>(kfr[f & 1]);
       }
       dq[f >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[f & 1], ds[(f >> 1) & 1][f & 1], dq[f >> 2], 0, 0, 0);
-    }
+    };
+    vy_static_for<8>(step);
   };
 
   // every ordinary load is retired before the first LDS-DMA (else the compiler's wait for it
@@ -557,12 +587,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(BwdParams p) {
   const int li = lane & 15, g16 = (lane >> 4) & 1;
   const int t_row = 4 * fh + (li >> 2);
   const int t_chunk = 2 * g16 + ((li & 3) >> 1), t_byte = 8 * (li & 1);
+  unsigned t_lds[2][2];  // transposed fragment of d block n, rows t_row (+8), ring buffer 0
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int row = t_row + 8 * u;
+      t_lds[n][u] = vy_lds_addr(smem) + row * RB + (((4 * n + t_chunk) ^ dual_sw(row)) << 4) + t_byte;
+    }
 
   auto compute = [&](int it, int buf) {
     const int hh = it / per_head, qt = qt_first + (it - hh * per_head);
     const char* qb_ = smem + buf * QT;
     const char* gb_ = smem + (NS + buf) * QT;
     const float* stl = reinterpret_cast<const float*>(smem + ST_OFF + buf * 512);
+    unsigned qbase_[2][2], gbase[2][2];  // transposed-read bases of this buffer (Q ring / dO ring)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        qbase_[n][u] = t_lds[n][u] + buf * QT;
+        gbase[n][u] = t_lds[n][u] + (NS + buf) * QT;
+      }
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       const int qbase = qt * QR + 32 * blk;
@@ -610,27 +656,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(BwdParams p) {
         }
       }
       // dV^T[d][key] += dO^T[d][q] . P[q][key];   dK^T[d][key] += Q^T[d][q] . dS[q][key]
-      auto frag = [&](const char* base, int f) {
-        const int n = f >> 1, row = 32 * blk + 16 * (f & 1) + t_row;
-        const int chunk = 4 * n + t_chunk;
-        return vy_lds_tr16_pair(base + row * RB + ((chunk ^ dual_sw(row)) << 4) + t_byte,
-                                base + (row + 8) * RB + ((chunk ^ dual_sw(row + 8)) << 4) + t_byte);
+      auto frag = [&](auto f_c, const unsigned (&base)[2][2]) {
+        constexpr int f = decltype(f_c)::value;
+        constexpr int n = f >> 1, ro = 16 * (f & 1) * RB;
+        union { struct { s16x4 a, b; } s_; bf16x8 v; } u;
+        u.s_.a = vy_lds_tr16_off<ro>(base[n][0] + 32 * blk * RB);
+        u.s_.b = vy_lds_tr16_off<ro>(base[n][1] + 32 * blk * RB);
+        return u.v;
       };
       bf16x8 gfr[2], qfr[2];
-      gfr[0] = frag(gb_, 0);
-      qfr[0] = frag(qb_, 0);
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        if (f + 1 < 4) {
-          gfr[(f + 1) & 1] = frag(gb_, f + 1);
-          qfr[(f + 1) & 1] = frag(qb_, f + 1);
+      gfr[0] = frag(std::integral_constant<int, 0>{}, gbase);
+      qfr[0] = frag(std::integral_constant<int, 0>{}, qbase_);
+      auto step = [&](auto f_c) {
+        constexpr int f = decltype(f_c)::value;
+        if constexpr (f + 1 < 4) {
+          gfr[(f + 1) & 1] = frag(std::integral_constant<int, f + 1>{}, gbase);
+          qfr[(f + 1) & 1] = frag(std::integral_constant<int, f + 1>{}, qbase_);
           vy_lgkm_wait<4>(gfr[f & 1], qfr[f & 1]);
         } else {
           vy_lgkm_wait<0>(gfr[f & 1], qfr[f & 1]);
         }
         dv[f >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gfr[f & 1], pf[f & 1], dv[f >> 1], 0, 0, 0);
         dk[f >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr[f & 1], dsf[f & 1], dk[f >> 1], 0, 0, 0);
-      }
+      };
+      vy_static_for<4>(step);
     }
   };
 
@@ -696,32 +745,28 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   static const int wv = [] { const char* e = getenv("VY_WGRAD_VARIANT"); return e ? atoi(e) : -1; }();
   static const int diag = [] { const char* e = getenv("VY_WGRAD_DIAG"); return e ? atoi(e) : 0; }();
   static const int tgt = [] { const char* e = getenv("VY_WGRAD_TARGET"); return e ? atoi(e) : 0; }();
-  const bool big = wv == 1;  // 256-wide tiles measured slower at every training shape (1 workgroup per CU)
-  const int BNt = big ? 256 : 128;
-  const int tiles_n = (int)vy_cdiv(N, BNt), tiles_k = (int)vy_cdiv(K, 128);
+  // wv: 0 = 128 x 128 (64-row stages), 1 = 256 x 128, 2 = 128(n) x 256(k) with 32-row stages
+  // (11.7 instead of 15.6 LDS-DMA bytes per kFLOP, still two workgroups per CU), 4 = the same, 3-deep ring
+  const int var = wv < 0 ? 0 : wv;  // 128 x 128 measured fastest at every training shape
+  const int BNt = var == 1 ? 256 : 128, BKt = (var == 2 || var == 4) ? 256 : 128;
+  const int tiles_n = (int)vy_cdiv(N, BNt), tiles_k = (int)vy_cdiv(K, BKt);
   const int tiles = tiles_n * tiles_k;
-  int64_t splits = vy_cdiv(tgt > 0 ? tgt : (big ? 256 : 384), tiles);  // ~1 (big) / ~1.5 (small) workgroups per CU
+  int64_t splits = vy_cdiv(tgt > 0 ? tgt : (var == 1 ? 256 : 384), tiles);  // ~1.5 workgroups per CU
   const int64_t max_splits = vy_cdiv(M, 256);                // >= 4 stages of 64 rows each
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int64_t m_chunk = vy_cdiv(vy_cdiv(M, splits), 64) * 64;
   splits = vy_cdiv(M, m_chunk);
   static const int ns = [] { const char* e = getenv("VY_WGRAD_STAGES"); return e ? atoi(e) : 2; }();
-  if (big && ns == 2)
-    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<256, 2>), dim3((unsigned)(tiles * splits)), dim3(512), 0, st, (const bf16*)dy,
-                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
-  else if (big)
-    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<256, 3>), dim3((unsigned)(tiles * splits)), dim3(512), 0, st, (const bf16*)dy,
-                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
-  else if (ns == 2)
-    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<128, 2>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
-                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
-  else if (ns == 4)
-    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<128, 4>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
-                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
-  else
-    hipLaunchKernelGGL((wgrad_tn_bf16_kernel<128, 3>), dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const bf16*)dy,
-                       lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk, diag);
+#define WG_GO(BN_, BK_, MS_, NS_)                                                                          \
+  hipLaunchKernelGGL((wgrad_tn_bf16_kernel<BN_, BK_, MS_, NS_>), dim3((unsigned)(tiles * splits)), dim3(BN_ * 2), 0, \
+                     st, (const bf16*)dy, lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, \
+                     (int)K, tiles_k, tiles, (int)m_chunk, diag)
+  if (var == 1) { if (ns == 3) WG_GO(256, 128, 64, 3); else WG_GO(256, 128, 64, 2); }
+  else if (var == 2) WG_GO(128, 256, 32, 2);
+  else if (var == 4) WG_GO(128, 256, 32, 3);
+  else { if (ns == 3) WG_GO(128, 128, 64, 3); else WG_GO(128, 128, 64, 2); }
+#undef WG_GO
   VY_CHECK_LAUNCH(who);
   return VY_OK;
 }

@@ -1,6 +1,7 @@
 // Common device/host helpers for libvyom_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <math.h>
@@ -30,12 +31,39 @@ __device__ __forceinline__ s16x4 vy_lds_tr16(const char* p) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"((unsigned)(uintptr_t)(VY_LDS const char*)p) : "memory");
   return r;
 }
+// the same with a compile-time byte offset in the instruction's 16-bit offset field: the asm form
+// hides the address from the compiler, so it cannot fold constants into that field itself and would
+// spend a v_add per read
+template <int OFF>
+__device__ __forceinline__ s16x4 vy_lds_tr16_off(unsigned lds_addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
+  return r;
+}
+template <int OFF0, int OFF1>
+__device__ __forceinline__ bf16x8 vy_lds_tr16_pair_off(unsigned lds_addr) {
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = vy_lds_tr16_off<OFF0>(lds_addr);
+  u.s.b = vy_lds_tr16_off<OFF1>(lds_addr);
+  return u.v;
+}
+__device__ __forceinline__ unsigned vy_lds_addr(const char* p) { return (unsigned)(uintptr_t)(VY_LDS const char*)p; }
 // rows r and r+8 of a transposed 16-row block -> one MFMA A/B fragment (2 LDS reads, no wait)
 __device__ __forceinline__ bf16x8 vy_lds_tr16_pair(const char* p0, const char* p1) {
   union { struct { s16x4 a, b; } s; bf16x8 v; } u;
   u.s.a = vy_lds_tr16(p0);
   u.s.b = vy_lds_tr16(p1);
   return u.v;
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant
+// expression in the body (instruction offset fields, register-array indices)
+template <int N, typename F>
+__device__ __forceinline__ void vy_static_for(F&& f) {
+  if constexpr (N > 0) {
+    vy_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
 }
 template <typename T>
 __device__ __forceinline__ void vy_tie(T& v) { asm volatile("" : "+v"(v)); }
