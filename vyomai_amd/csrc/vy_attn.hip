@@ -40,6 +40,7 @@ struct AttnParams {
   int B, h, hk, L, S;
   float scale;
   const int* pos_dev;  // decode under a hipGraph: S = *pos_dev + 1 (else NULL)
+  int diag;            // timing experiments only (VY_ATTN_DIAG): 1 = no output store, 2 = no tile loop
 };
 
 // ------------------------------------------------------------------------------------------
@@ -61,8 +62,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (p.L + 127) / 128;
-  const int qb = nqb - 1 - (int)blockIdx.x;  // heaviest (most keys under a causal mask) first
-  const int head = blockIdx.y, b = blockIdx.z;
+  // grid = (h*B, query blocks): the dispatcher walks x first, so ALL the heaviest query blocks
+  // (most keys under a causal mask) of every (batch, head) start before any lighter one --
+  // longest-processing-time order; with (query block, head, batch) order the last (batch, head)
+  // groups still start full-length workgroups at the very end and causal ran as long as full
+  const int qb = nqb - 1 - (int)blockIdx.y;
+  const int head = (int)blockIdx.x % p.h, b = (int)blockIdx.x / p.h;
   const int kvh = head / (p.h / p.hk);
   const int q0 = qb * 128;
   const int fr = lane & 31, fh = lane >> 5;
@@ -73,10 +78,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   const bf16* Kb = (const bf16*)p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
   const bf16* Vb = (const bf16*)p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
 
-  bf16x8 qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + ks * 16 + fh * 8);
-
+  bf16x8 qf[KS];  // loaded after the first K/V tiles are in flight (below)
   const bool causal = p.mask_kind & VY_MASK_CAUSAL;
   const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
   const bool hasadd = p.mask_kind & VY_MASK_ADDITIVE;
@@ -162,16 +164,34 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     const char* kb_ = smem + buf * TILE;
     const char* vb_ = smem + (NS + buf) * TILE;
     f32x16 st[2];
+    // all K fragments of the tile are requested before the first MFMA (one exposed LDS latency per
+    // tile instead of one per k-step)
+    bf16x8 kfr[2][KS];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        kfr[kb][ks] = *reinterpret_cast<const bf16x8*>(kb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ k_sw) << 4));
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ k_sw) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
-      }
+      for (int ks = 0; ks < KS; ++ks)
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ks], qf[ks], st[kb], 0, 0, 0);
     }
+    // V^T fragments: asm transposing reads (see vy_common.h), ALL requested here so that they land
+    // under the softmax arithmetic below and the P.V MFMAs run back to back.  One base address per
+    // 32-wide d block; key block, k-step and the +8 row go into the offset field.
+    unsigned vbase[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n) vbase[n] = v_lds[n] + buf * TILE;
+    bf16x8 vfr[4 * ND];
+    vy_static_for<4 * ND>([&](auto f_c) {
+      constexpr int f = decltype(f_c)::value;
+      constexpr int n = f >> 2, kb = (f >> 1) & 1, s = f & 1;
+      vfr[f] = vy_lds_tr16_pair_off<NS * TILE + (32 * kb + 16 * s) * RB, NS * TILE + (32 * kb + 16 * s + 8) * RB>(vbase[n]);
+    });
     unsigned long long vis = ~0ull;
     if (haskp) vis = kpbits[tile];
     const bool need_mask = hasadd || (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first) || vis != ~0ull;
@@ -243,29 +263,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[kb][s][j] = (bf16)st[kb][8 * s + j];
-    // V^T fragments: asm transposing reads (see vy_common.h), one fragment ahead of its MFMA.  One
-    // base address per 32-wide d block; key block, k-step and the +8 row go into the offset field.
-    unsigned vbase[ND];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int n = 0; n < ND; ++n) vbase[n] = v_lds[n] + buf * TILE;
-    auto vfrag = [&](auto f_c) {
-      constexpr int f = decltype(f_c)::value;
-      constexpr int n = f >> 2, kb = (f >> 1) & 1, s = f & 1;
-      return vy_lds_tr16_pair_off<NS * TILE + (32 * kb + 16 * s) * RB, NS * TILE + (32 * kb + 16 * s + 8) * RB>(vbase[n]);
-    };
-    bf16x8 vfr[2];
-    vfr[0] = vfrag(std::integral_constant<int, 0>{});
-    auto pv = [&](auto f_c) {
-      constexpr int f = decltype(f_c)::value;
-      if constexpr (f + 1 < 4 * ND) {
-        vfr[(f + 1) & 1] = vfrag(std::integral_constant<int, f + 1>{});
-        vy_lgkm_wait<2>(vfr[f & 1]);
-      } else {
-        vy_lgkm_wait<0>(vfr[f & 1]);
-      }
-      o[f >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[f & 1], pf[(f >> 1) & 1][f & 1], o[f >> 2], 0, 0, 0);
-    };
-    vy_static_for<4 * ND>(pv);
+    for (int f = 0; f < 4 * ND; ++f) vy_tie(vfr[f]);
+#pragma unroll
+    for (int f = 0; f < 4 * ND; ++f)
+      o[f >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[f], pf[(f >> 1) & 1][f & 1], o[f >> 2], 0, 0, 0);
   };
 
   // Loads run NS-1 tiles ahead of the MFMAs: a tile is waited for with a COUNTED vmcnt (its own
@@ -284,11 +287,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   // reads them), before any LDS-DMA is in flight -- otherwise its wait for them sits at the first
   // MFMA inside the loop as vmcnt(0) and drains the ring every tile.
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
-#pragma unroll
   for (int s_ = 0; s_ < NS - 1; ++s_)
     if (s_ < nt) stage(s_, s_);
-  for (int t = 0; t < nt; ++t) {
+  // Q after the first K/V tiles are requested: one memory latency for both, not two in a row
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + ks * 16 + fh * 8);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(qf[ks]));
+  for (int t = 0; t < (p.diag == 2 ? 0 : nt); ++t) {
     wait_tile(min(NS - 2, nt - 1 - t));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -341,6 +347,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     }
   }
   const float inv = 1.0f / l_tot;
+  if (p.diag == 1 && o[0][0] != 12345.678f) return;
   if (qi < p.L) {
     bf16* O = (bf16*)p.out + (int64_t)b * p.o_sb + (int64_t)qi * p.o_sl + head * DH;
 #pragma unroll
@@ -553,12 +560,14 @@ extern "C" int vy_attn_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   p.mask_kind = mask_kind; p.start_pos = (int)start_pos;
   p.keypad = keypad; p.kp_sb = kp_sb; p.addmask = addmask; p.am_sb = am_sb; p.am_sl = am_sl;
   p.B = (int)B; p.h = h; p.hk = hk; p.L = (int)L; p.S = (int)S; p.scale = scale; p.pos_dev = nullptr;
+  static const int diag = [] { const char* e = getenv("VY_ATTN_DIAG"); return e ? atoi(e) : 0; }();
+  p.diag = diag;
   if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
   if (int rc = check_attn(who, p, dh, dtype)) return rc;
   hipStream_t st = (hipStream_t)stream;
   // (the key-padding visibility words of the MFMA kernel cover 16384 keys)
   if (dtype == VY_BF16 && (dh == 64 || dh == 128) && L > 1 && !((mask_kind & VY_MASK_KEYPAD) && S > 16384)) {
-    const dim3 grid((unsigned)((L + 127) / 128), (unsigned)h, (unsigned)B), block(256);
+    const dim3 grid((unsigned)(h * B), (unsigned)((L + 127) / 128), 1), block(256);
     if (dh == 64) hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_mfma_kernel<128>, grid, block, 0, st, p);
     VY_CHECK_LAUNCH(who);

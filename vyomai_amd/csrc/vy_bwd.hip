@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (p.L + 127) / 128;
-  const int qb = nqb - 1 - (int)blockIdx.x;
-  const int head = blockIdx.y, b = blockIdx.z;
+  const int qb = nqb - 1 - (int)blockIdx.y;  // grid (h*B, query blocks): heaviest blocks of ALL heads first
+  const int head = (int)blockIdx.x % p.h, b = (int)blockIdx.x / p.h;
   const int kvh = head / (p.h / p.hk);
   const int q0 = qb * 128;
   const int fr = lane & 31, fh = lane >> 5;
@@ -477,11 +477,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdParams p) {
   // every ordinary load is retired before the first LDS-DMA (else the compiler's wait for it
   // becomes a vmcnt(0) inside the loop and drains the ring every tile)
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { vy_tie(qf[ks]); vy_tie(gf[ks]); }
-  vy_tie(neg_lse); vy_tie(neg_delta);
-#pragma unroll
   for (int s_ = 0; s_ < NS - 1; ++s_)
     if (s_ < nt) stage(s_, s_);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { vy_tie(qf[ks]); vy_tie(gf[ks]); }
+  vy_tie(neg_lse); vy_tie(neg_delta);
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -519,7 +519,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(BwdParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * NS * QT + NS * 512];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kblk = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+  // grid (hk*B, key blocks): key block 0 sees every query row under a causal mask -> all of them first
+  const int kblk = blockIdx.y, kvh = (int)blockIdx.x % p.hk, b = (int)blockIdx.x / p.hk;
   const int n_rep = p.h / p.hk;
   const int fr = lane & 31, fh = lane >> 5;
   const int key0 = kblk * 128 + wave * 32;
@@ -684,10 +685,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(BwdParams p) {
   };
 
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { vy_tie(kf[ks]); vy_tie(vf[ks]); }
-#pragma unroll
   for (int s_ = 0; s_ < NS - 1; ++s_)
     if (s_ < total) stage(s_, s_);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { vy_tie(kf[ks]); vy_tie(vf[ks]); }
   for (int it = 0; it < total; ++it) {
     if (it + 1 < total) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -808,9 +809,9 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)vy_cdiv(B * L, 4)), dim3(256), 0, st, p);
   VY_CHECK_LAUNCH("vy_attn_bwd(delta)");
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((L + 127) / 128), (unsigned)h, (unsigned)B), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(h * B), (unsigned)((L + 127) / 128), 1), dim3(256), 0, st, p);
   VY_CHECK_LAUNCH("vy_attn_bwd(dq)");
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)((S + 127) / 128), (unsigned)hk, (unsigned)B), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(hk * B), (unsigned)((S + 127) / 128), 1), dim3(256), 0, st, p);
   VY_CHECK_LAUNCH("vy_attn_bwd(dkdv)");
   return VY_OK;
 }
