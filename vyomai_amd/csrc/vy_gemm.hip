@@ -770,6 +770,155 @@ __global__ __launch_bounds__(256) void gemm_skinny_bf16_kernel(
   }
 }
 
+// ---- split-K weight streaming for M <= 32 and narrow N (decode: N = hidden size) --------------
+// A skinny GEMM has N/32 workgroups: 24 for N = 768, on a 256-CU chip.  Here grid.y slices of K
+// each produce an fp32 partial tile part[ks][32][N] (plain stores: deterministic, no atomics); the
+// consumer (splitk_finish_ln_kernel) adds them in slice order with bias and residual.
+__global__ __launch_bounds__(256) void gemm_skinny_splitk_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int steps_per_wg, float* __restrict__ part) {
+  __shared__ float red[3][16][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nb = blockIdx.x, ks = blockIdx.y;
+  const int col = nb * 32 + fr;
+  const int wr = col < N ? col : N - 1;
+  const int mr = fr < M ? fr : M - 1;
+  const bf16* wp = W + (int64_t)wr * ldw + fh * 8;
+  const bf16* xp = X + (int64_t)mr * ldx + fh * 8;
+  const int nsteps = K >> 4;
+  const int s_end = min(nsteps, (ks + 1) * steps_per_wg);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int s = ks * steps_per_wg + wave;
+  for (; s + 20 < s_end; s += 24) {  // 6 k-steps of this wave per trip: 12 loads in flight
+    bf16x8 a[6], b[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      a[u] = *reinterpret_cast<const bf16x8*>(wp + 16 * (s + 4 * u));
+      b[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 4 * u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; s + 4 < s_end; s += 8) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      a[u] = *reinterpret_cast<const bf16x8*>(wp + 16 * (s + 4 * u));
+      b[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 4 * u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; s < s_end; s += 4) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(wp + 16 * s);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+  if (fr >= M) return;
+  float* dst = part + ((int64_t)ks * 32 + fr) * N + nb * 32 + 4 * fh;
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const f32x4 v = {acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]};
+    *reinterpret_cast<f32x4*>(dst + 8 * rg) = v;
+  }
+}
+
+// y = LayerNorm(bf16(sum_ks part[ks] + bias + residual)): the epilogue of the split-K GEMM above fused
+// with the LayerNorm that follows it in the block (AttentionSelfOutput / FeedForward).  One wave per
+// row, the same arithmetic as gemm epilogue + layernorm_fwd_kernel (sum rounded to bf16 first).
+template <int CH>
+__global__ __launch_bounds__(256) void splitk_finish_ln_kernel(const float* __restrict__ part, int ksplit, int M,
+                                                               int N, const bf16* __restrict__ bias,
+                                                               const bf16* __restrict__ residual, int64_t ldr,
+                                                               const bf16* __restrict__ gamma,
+                                                               const bf16* __restrict__ beta, bf16* __restrict__ y,
+                                                               int64_t ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = N / 8;
+  float v[CH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      float a[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = 0.f;
+      // all (<= 8) partial tiles are requested before the first add: one memory latency, not ksplit
+      f32x4 p0[8], p1[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float* pp = part + ((int64_t)(k < ksplit ? k : 0) * 32 + row) * N + ch * 8;
+        p0[k] = *reinterpret_cast<const f32x4*>(pp);
+        p1[k] = *reinterpret_cast<const f32x4*>(pp + 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k < ksplit) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[e] += p0[k][e]; a[4 + e] += p1[k][e]; }
+        }
+      }
+      if (bias) {
+        const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(bias + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += (float)b8[e];
+      }
+      if (residual) {
+        const bf16x8 r8 = *reinterpret_cast<const bf16x8*>(residual + (int64_t)row * ldr + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += (float)r8[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[c][e] = vy_round_bf16(a[e]); s += v[c][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+    }
+  }
+  const float mean = vy_wave_sum(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+    }
+  }
+  const float var = vy_wave_sum(q) / (float)N;
+  const float rstd = rsqrtf(var + eps);
+  const float rstd_r = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nch) {
+      const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gamma + ch * 8);
+      const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(beta + ch * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[c][e] - mean) * rstd_r * (float)g8[e] + (float)b8[e]);
+      *reinterpret_cast<bf16x8*>(y + (int64_t)row * ldy + ch * 8) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // f32 MFMA kernel (parity path): 64x64 tile, BK=16, 4 waves of 32x32, mfma_f32_32x32x2f32
 // ------------------------------------------------------------------------------------------
@@ -1049,6 +1198,43 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
 }
 
 // internal: vy_qkv_rope_fwd with the token position read from device memory (graph replay)
+// y = LN(x W^T + bias + residual) for M <= 32 rows (decode), bf16: split-K GEMM + fused finish.
+// `part` is an fp32 scratch of vy_splitk_ws_floats(N) elements.  Internal to the decode driver.
+int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N; }
+int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                            const void* residual, int64_t ldr, const void* gamma, const void* beta, float eps,
+                            void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream) {
+  const char* who = "vy_linear_res_ln_skinny";
+  if (!x || !w || !gamma || !beta || !y || !part) VY_FAIL(VY_ERR_ARG, "%s: null operand", who);
+  if (M < 1 || M > 32 || N % 32 || K % 16 || N > 8192) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: needs M <= 32, N %% 32 == 0 (<= 8192), K %% 16 == 0", who);
+  if (ldx % 8 || ldw % 8 || ldy % 8 || (residual && ldr % 8)) VY_FAIL(VY_ERR_ARG, "%s: strides must be multiples of 8", who);
+  hipStream_t st = (hipStream_t)stream;
+  const int nsteps = (int)(K / 16), nwg = (int)(N / 32);
+  int ksplit = (256 + nwg - 1) / nwg;            // ~one workgroup per CU
+  if (ksplit > 8) ksplit = 8;
+  if (ksplit > nsteps / 8) ksplit = nsteps / 8;  // >= 8 k-steps (two per wave) per workgroup
+  if (ksplit < 1) ksplit = 1;
+  int spw = (nsteps + ksplit - 1) / ksplit;
+  spw = (spw + 3) / 4 * 4;
+  ksplit = (nsteps + spw - 1) / spw;
+  hipLaunchKernelGGL(gemm_skinny_splitk_kernel, dim3((unsigned)nwg, (unsigned)ksplit), dim3(256), 0, st, (const bf16*)x,
+                     ldx, (const bf16*)w, ldw, (int)M, (int)N, (int)K, spw, part);
+  VY_CHECK_LAUNCH(who);
+  const int nch = (int)(N / 8);
+  const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+#define FIN_GO(CH)                                                                                               \
+  hipLaunchKernelGGL((splitk_finish_ln_kernel<CH>), grid, block, 0, st, part, ksplit, (int)M, (int)N, (const bf16*)bias, \
+                     (const bf16*)residual, ldr, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, ldy, eps)
+  if (nch <= 64) FIN_GO(1);
+  else if (nch <= 128) FIN_GO(2);
+  else if (nch <= 256) FIN_GO(4);
+  else if (nch <= 512) FIN_GO(8);
+  else FIN_GO(16);
+#undef FIN_GO
+  VY_CHECK_LAUNCH(who);
+  return VY_OK;
+}
+
 int vy_qkv_rope_fwd_ex(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                        const float* cos_tab, const float* sin_tab, int64_t pos0, const int* pos_dev, void* q,
                        int64_t q_sb, int64_t q_sh, int64_t q_sl, void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,

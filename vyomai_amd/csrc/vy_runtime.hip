@@ -12,6 +12,11 @@ int vy_attn_decode_ex(const void* q, int64_t q_sb, int64_t q_sh, const void* k, 
                       int64_t o_sb, int64_t B, int h, int hk, int64_t S, const int* pos_dev, int dh, float scale,
                       int dtype, void* stream);
 
+int64_t vy_splitk_ws_floats(int64_t N);
+int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                            const void* residual, int64_t ldr, const void* gamma, const void* beta, float eps,
+                            void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream);
+
 namespace {
 inline int64_t esize(int dtype) { return dtype == VY_BF16 ? 2 : 4; }
 inline int64_t up(int64_t x) { return (x + 255) / 256 * 256; }
@@ -20,8 +25,9 @@ inline int64_t up(int64_t x) { return (x + 255) / 256 * 256; }
 extern "C" int64_t vy_decode_ws_bytes(int32_t B, int32_t d, int32_t h, int32_t hk, int32_t dh, int32_t ffn,
                                       int32_t dtype) {
   const int64_t e = esize(dtype);
-  // q, attn out, s (pre-LN), a (post-LN1), mid (ffn), two ping-pong hidden buffers
-  return up(B * (int64_t)h * dh * e) + 5 * up(B * (int64_t)d * e) + up(B * (int64_t)ffn * e) + 4096;
+  // q, attn out, s (pre-LN), a (post-LN1), mid (ffn), two ping-pong hidden buffers, split-K partials
+  return up(B * (int64_t)h * dh * e) + 5 * up(B * (int64_t)d * e) + up(B * (int64_t)ffn * e) +
+         up(vy_splitk_ws_floats(d) * 4) + 4096;
 }
 
 extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t pos, const int32_t* pos_dev,
@@ -40,7 +46,11 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
   void* hb[2];
   hb[0] = w; w += up(B * (int64_t)d * e);
   hb[1] = w; w += up(B * (int64_t)d * e);
-  void* mid = w;
+  void* mid = w; w += up(B * (int64_t)p->ffn * e);
+  float* part = (float*)w;
+  // M <= 32 rows in bf16: the two N = d projections (24 workgroups as plain skinny GEMMs) run split-K
+  // over ~all CUs, their bias + residual + LayerNorm fused into the kernel that adds the partials
+  const bool splitk = p->dtype == VY_BF16 && B <= 32 && d % 32 == 0 && d <= 8192 && p->ffn % 16 == 0;
   const float scale = 1.0f / sqrtf((float)dh);
   const void* cur = x;
   for (int l = 0; l < p->num_layers; ++l) {
@@ -58,18 +68,29 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
     rc = vy_attn_decode_ex(q, (int64_t)h * dh, dh, L.kcache, L.c_sb, L.c_sh, L.c_sl, L.vcache, L.c_sb, L.c_sh,
                            L.c_sl, ao, d, B, h, hk, pos + 1, pos_dev, dh, scale, p->dtype, stream);
     if (rc) return rc;
-    rc = vy_linear_fwd(ao, d, L.wo, d, L.bo, cur, d, s, d, nullptr, B, d, d, VY_ACT_NONE, p->dtype, stream);
-    if (rc) return rc;
-    rc = vy_layernorm_fwd(s, d, L.ln1_w, L.ln1_b, a, d, nullptr, nullptr, B, d, p->eps_attn, p->dtype, stream);
-    if (rc) return rc;
+    if (splitk) {
+      rc = vy_linear_res_ln_skinny(ao, d, L.wo, d, L.bo, cur, d, L.ln1_w, L.ln1_b, p->eps_attn, a, d, part, B, d, d, stream);
+      if (rc) return rc;
+    } else {
+      rc = vy_linear_fwd(ao, d, L.wo, d, L.bo, cur, d, s, d, nullptr, B, d, d, VY_ACT_NONE, p->dtype, stream);
+      if (rc) return rc;
+      rc = vy_layernorm_fwd(s, d, L.ln1_w, L.ln1_b, a, d, nullptr, nullptr, B, d, p->eps_attn, p->dtype, stream);
+      if (rc) return rc;
+    }
     rc = vy_linear_fwd(a, d, L.w1, d, L.b1, nullptr, 0, mid, p->ffn, nullptr, B, p->ffn, d, p->act, p->dtype, stream);
     if (rc) return rc;
     // FFN residual = the LAYER INPUT (reference models/decoder.py:241-250)
-    rc = vy_linear_fwd(mid, p->ffn, L.w2, p->ffn, L.b2, cur, d, s, d, nullptr, B, d, p->ffn, VY_ACT_NONE, p->dtype, stream);
-    if (rc) return rc;
     void* nxt = hb[l & 1];
-    rc = vy_layernorm_fwd(s, d, L.ln2_w, L.ln2_b, nxt, d, nullptr, nullptr, B, d, p->eps_ffn, p->dtype, stream);
-    if (rc) return rc;
+    if (splitk) {
+      rc = vy_linear_res_ln_skinny(mid, p->ffn, L.w2, p->ffn, L.b2, cur, d, L.ln2_w, L.ln2_b, p->eps_ffn, nxt, d, part, B,
+                                   d, p->ffn, stream);
+      if (rc) return rc;
+    } else {
+      rc = vy_linear_fwd(mid, p->ffn, L.w2, p->ffn, L.b2, cur, d, s, d, nullptr, B, d, p->ffn, VY_ACT_NONE, p->dtype, stream);
+      if (rc) return rc;
+      rc = vy_layernorm_fwd(s, d, L.ln2_w, L.ln2_b, nxt, d, nullptr, nullptr, B, d, p->eps_ffn, p->dtype, stream);
+      if (rc) return rc;
+    }
     cur = nxt;
   }
   if (hidden_out && hidden_out != cur) {
