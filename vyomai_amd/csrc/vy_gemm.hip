@@ -369,7 +369,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
 template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
-    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq, int rot_on) {
   constexpr int NW = WGM * WGN, NT = 64 * NW;
   constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
   static_assert(TM * 32 * WGM == BM && TN * 32 * WGN == BN, "tile / wave layout mismatch");
@@ -411,10 +411,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
   const bool ktail = (K % BK) != 0;
   const int KT = (K + BK - 1) / BK;
 
+  // optional (VY_GEMM_ROT=1) per-tile rotated k order, an experiment: workgroups that share an operand
+  // run in lockstep and request the same not-yet-resident lines at once.  tools/probe/ldsdma_probe
+  // shows the L2 merges such requests well (72 GB/s per CU for a 4-way shared stream against 28
+  // unshared), and the rotation measured 1-5 % slower -- kept off.
+  const int rot = rot_on ? (tile_n * 2 + tile_m) % KT : 0;
   auto stage = [&](int kt, int buf) {
     char* xb = smem + buf * STAGE;
     char* wb = xb + BM * ROWB;
-    const int k0 = kt * BK;
+    int kr = kt + rot;
+    kr = kr >= KT ? kr - KT : kr;
+    const int k0 = kr * BK;
 #pragma unroll
     for (int t = 0; t < GX; ++t) {
       if (PX % NW == 0 || wave + NW * t < PX) {
@@ -986,17 +993,18 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
 template <int EPI, int ACT, bool GRAD>
 int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t M, int64_t N,
                 int64_t K, const EpiPlain<bf16>& ep, const EpiQkv<bf16>& eq, hipStream_t st) {
+  static const int rot = [] { const char* e = getenv("VY_GEMM_ROT"); return e ? atoi(e) : 0; }();  // rotated k order: measured 1-5 % slower
   if (M <= 32 && K % 16 == 0 && !GRAD && (EPI == 0 || !eq.rope || N % 64 == 0)) {
     hipLaunchKernelGGL((gemm_skinny_bf16_kernel<EPI, ACT>), dim3((unsigned)vy_cdiv(N, 32)), dim3(256), 0, st, X, ldx,
                        W, ldw, (int)M, (int)N, (int)K, ep, eq);
   } else if (M <= 32) {  // skinny fallback: 32 x 128 tiles
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 32);
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<32, 128, 1, 4, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
-                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
   } else if (M <= 1024) {
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
-                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
   } else {
     const int tn = (int)vy_cdiv(N, 192), tm = (int)vy_cdiv(M, 256);
     // default: 2-stage 64-deep tiles.  256 x 192 divides N in {768, 2304} x M = 16384 into whole
@@ -1008,21 +1016,21 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     if (var == 8 || (var < 0 && wide)) {
       const int tn2 = (int)vy_cdiv(N, 256);
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq);
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
     } else if (var == 10) {  // 4 waves, 128 x 128 per wave: fewest LDS bytes per FLOP
       const int tn2 = (int)vy_cdiv(N, 256);
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(256), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq);
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
     } else if (var == 12) {  // 128 x 192, 4 waves, 80 KiB LDS: two workgroups per CU overlap epilogue and main loop
       const int tm2 = (int)vy_cdiv(M, 128);
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm2 * tn), dim3(256), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     } else if (var == 11) {  // 4 waves, 128 x 96 per wave
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     } else if (var == 9 || var < 0) {
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     } else if (var == 1) {
       hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 1, 4>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
