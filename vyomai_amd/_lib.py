@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvyom_hip.so")
+# VY_LIB_PATH: developer knob for A/B runs of two builds of the same ABI on one box (tools/ab_lib.sh)
+LIB_PATH = os.environ.get("VY_LIB_PATH") or os.path.join(_HERE, "lib", "libvyom_hip.so")
 
 VY_F32, VY_BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2

@@ -48,6 +48,16 @@ __device__ __forceinline__ bf16x8 vy_lds_tr16_pair_off(unsigned lds_addr) {
   u.s.b = vy_lds_tr16_off<OFF1>(lds_addr);
   return u.v;
 }
+// ds_read_b128 in the same hidden form: hipcc retires its own LDS reads with lgkmcnt(0), which also
+// waits for the fragments just requested for the NEXT k-step; hidden reads are retired by the caller
+// with a counted lgkmcnt, so a k-step's MFMAs wait only for their own operands.
+template <int OFF>
+__device__ __forceinline__ bf16x8 vy_lds_read128_off(unsigned lds_addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
+  return r;
+}
 __device__ __forceinline__ unsigned vy_lds_addr(const char* p) { return (unsigned)(uintptr_t)(VY_LDS const char*)p; }
 // rows r and r+8 of a transposed 16-row block -> one MFMA A/B fragment (2 LDS reads, no wait)
 __device__ __forceinline__ bf16x8 vy_lds_tr16_pair(const char* p0, const char* p1) {

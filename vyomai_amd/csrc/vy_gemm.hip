@@ -455,31 +455,52 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
   const int xrow_off = (wm * 32 * TM + fr) * ROWB;
   const int wrow_off = (wn * 32 * TN + fr) * ROWB;
 
-  stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0)
-  __syncthreads();
-
-  // fragments are double-buffered in registers: the reads of k-step ks+1 are issued before the
-  // MFMAs of k-step ks, so the LDS latency is exposed once per 64-wide tile, not four times
-  bf16x8 wf[2][TN], xf[2][TM];
-  auto read_frags = [&](int buf, int ks, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
-    const char* xb = smem + buf * STAGE;
-    const char* wb = xb + BM * ROWB;
+  // Fragments are double-buffered in registers: the reads of k-step ks+1 are issued before the MFMAs
+  // of k-step ks.  The reads are the hidden asm form (vy_common.h): hipcc would retire its own
+  // ds_reads with lgkmcnt(0), i.e. wait for the fragments it has JUST requested as well, exposing
+  // the LDS latency on every other k-step; here a k-step waits with a counted lgkmcnt for exactly
+  // its own TN + TM reads.  One base address per (buffer, k-step); the 32-row fragment index goes
+  // into the instruction's offset field.
+  unsigned xa[4], wa[4];  // buffer 0; buffer 1 is + STAGE (an add per stage, not a register-array index)
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
     const int coff = (((ks * 2 + fh) ^ fsw) << 4);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-      w_[i] = *reinterpret_cast<const bf16x8*>(wb + wrow_off + i * 32 * ROWB + coff);
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-      x_[j] = *reinterpret_cast<const bf16x8*>(xb + xrow_off + j * 32 * ROWB + coff);
+    xa[ks] = vy_lds_addr(smem) + xrow_off + coff;
+    wa[ks] = vy_lds_addr(smem) + BM * ROWB + wrow_off + coff;
+  }
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; w_[i] = vy_lds_read128_off<i * 32 * ROWB>(wbase); });
+    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; x_[j] = vy_lds_read128_off<j * 32 * ROWB>(xbase); });
   };
-  read_frags(0, 0, wf[0], xf[0]);
+  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) vy_tie(w_[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) vy_tie(x_[j]);
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(wa[0], xa[0], wf[0], xf[0]);
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+    const unsigned boff = cur * STAGE;
+    unsigned xb4[4], wb4[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { xb4[ks] = xa[ks] + boff; wb4[ks] = wa[ks] + boff; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) read_frags(cur, ks + 1, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+      if (ks < 3) {
+        read_frags(wb4[ks + 1], xb4[ks + 1], wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      tie_frags(wf[ks & 1], xf[ks & 1]);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
@@ -488,9 +509,144 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (kt + 1 < KT) read_frags(cur ^ 1, 0, wf[0], xf[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < KT) read_frags(wa[0] + (STAGE - boff), xa[0] + (STAGE - boff), wf[0], xf[0]);
+  }
+  // the epilogue reuses the stage buffers: every LDS read above has been retired (last k-step: lgkmcnt(0))
+  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
+}
+
+// ------------------------------------------------------------------------------------------
+// 256 x BN x 64 tile, 8 waves (4 x 2), with the X operand in a THREE-deep LDS ring and W in two
+// buffers (3*32 + 2*BN/8 KiB = 144 KiB at BN = 192).  Why: with two whole stages every workgroup
+// barrier drains the memory pipe (all waves issue, then all wait), and the pipe is busy about half
+// the time; tools/probe/ldsdma_probe shows free-running waves take in twice as much.  A third whole
+// stage does not fit in 160 KiB, but X -- 57 % of the bytes and the operand that streams from
+// HBM/MALL rather than from L2 -- does: its loads for k-slice kt+2 stay in flight across the
+// barrier that ends slice kt, and the barrier wait is a COUNTED vmcnt (the GX youngest LDS-DMA
+// instructions of the wave, slice kt+2 of X, may still be outstanding).
+// ------------------------------------------------------------------------------------------
+template <int BN, int EPI, int ACT, bool GRAD>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+  constexpr int BM = 256, WGM = 4, WGN = 2, NW = 8;
+  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+  constexpr int PX = BM / 8, PW = BN / 8;   // 1-KiB LDS-DMA pieces (8 rows x 128 B) per k-slice
+  constexpr int GX = PX / NW, GW = PW / NW;
+  static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
+  constexpr int XT = BM * ROWB, WT = BN * ROWB;        // bytes of one X / W k-slice
+  constexpr int WOFF = 3 * XT;
+  constexpr int EROW = BN * 2 + 16;
+  constexpr int LDS_BYTES = 3 * XT + 2 * WT > BM * EROW ? 3 * XT + 2 * WT : BM * EROW;
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lrow = lane >> 3, slot = lane & 7;
+  const bf16* xsrc[GX]; int xk[GX];
+  const bf16* wsrc[GW]; int wk[GW];
+#pragma unroll
+  for (int t = 0; t < GX; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gm = m0 + R; gm = gm < M ? gm : M - 1;
+    xsrc[t] = X + (int64_t)gm * ldx + g * 8;
+    xk[t] = g * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gn = n0 + R; gn = gn < N ? gn : N - 1;
+    wsrc[t] = W + (int64_t)gn * ldw + g * 8;
+    wk[t] = g * 8;
+  }
+  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
+  const bool ktail = (K % BK) != 0;
+  const int KT = (K + BK - 1) / BK;
+
+  auto stage_x = [&](int kt) {
+    char* xb = smem + (kt % 3) * XT;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int t = 0; t < GX; ++t) {
+      const bf16* s = xsrc[t] + k0;
+      if (ktail && k0 + xk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_w = [&](int kt) {
+    char* wb = smem + WOFF + (kt & 1) * WT;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int t = 0; t < GW; ++t) {
+      const bf16* s = wsrc[t] + k0;
+      if (ktail && k0 + wk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  const int xrow_off = (wm * 32 * TM + fr) * ROWB;
+  const int wrow_off = (wn * 32 * TN + fr) * ROWB;
+
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](int kt, int ks, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    const char* xb = smem + (kt % 3) * XT;
+    const char* wb = smem + WOFF + (kt & 1) * WT;
+    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+      w_[i] = *reinterpret_cast<const bf16x8*>(wb + wrow_off + i * 32 * ROWB + coff);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+      x_[j] = *reinterpret_cast<const bf16x8*>(xb + xrow_off + j * 32 * ROWB + coff);
+  };
+
+  // the wave's LDS-DMA queue, oldest first, at the wait that ends slice kt: X(kt+1), W(kt+1), X(kt+2)
+  stage_x(0);
+  stage_w(0);
+  if (KT > 1) stage_x(1);
+  if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, 0, wf[0], xf[0]);
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) stage_w(kt + 1);
+    if (kt + 2 < KT) stage_x(kt + 2);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) read_frags(kt, ks + 1, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < KT) read_frags(kt + 1, 0, wf[0], xf[0]);
   }
   gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
 }
@@ -1028,6 +1184,9 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     } else if (var == 11) {  // 4 waves, 128 x 96 per wave
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
+    } else if (var == 13) {  // X in a 3-deep ring (counted waits across the barrier), W in two buffers
+      hipLaunchKernelGGL((gemm_nt_bf16_x3_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
     } else if (var == 9 || var < 0) {
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
