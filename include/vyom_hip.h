@@ -216,6 +216,15 @@ int vy_xent_fused(void* logits, int64_t ld, const int64_t* labels, int64_t ignor
                   float* loss_sum, const float* count, const float* gscale, int64_t M, int64_t V,
                   int dtype, void* stream);
 
+/* Token embedding (nn.Embedding: VyomAI/models/decoder.py:287, encoder.py:41, multimodel.py):
+ * fwd: out[m,:] = table[ids[m],:] (bf16 or fp32).  Ids outside [0,V) give a zero row and set the
+ *      optional device flag *err_flag to 1 (the host cannot check ids without a sync).
+ * bwd: dW[ids[m],:] += dOut[m,:] in fp32 (atomics), except for id == padding_idx (pass -1 for none). */
+int vy_embedding_fwd(const void* table, int64_t ldt, const int64_t* ids, void* out, int64_t ldo,
+                     int64_t M, int64_t d, int64_t V, int32_t* err_flag, int dtype, void* stream);
+int vy_embedding_bwd(const void* dout, int64_t lddo, const int64_t* ids, float* dw, int64_t lddw,
+                     int64_t padding_idx, int64_t M, int64_t d, int64_t V, int dtype, void* stream);
+
 /* out[c, r] = in[r, c] for a [R,C] matrix (bf16 or f32): keeps W^T copies for dgrad. */
 int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t R, int64_t C,
                  int dtype, void* stream);

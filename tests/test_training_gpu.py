@@ -161,3 +161,28 @@ def test_lm_head_loss_upstream_gradient_scale():
         grads.append(tr.arena.grad.clone())
     err = (grads[1] - 0.25 * grads[0]).abs().max() / grads[0].abs().max()
     assert err < 2e-2, err
+
+
+def test_embedding_kernels():
+    """vy_embedding_fwd/bwd == F.embedding and its autograd (padding row gets no gradient)."""
+    from vyomai_amd import ops
+    g = torch.Generator().manual_seed(3)
+    V, d, M = 1031, 768, 500
+    for dt in (torch.float32, BF):
+        table = torch.randn(V, d, generator=g).to(dt).to(DEV)
+        ids = torch.randint(0, V, (5, 100), generator=g).to(DEV)
+        ids[0, :7] = 3
+        out = ops.embedding(table, ids)
+        assert torch.equal(out, torch.nn.functional.embedding(ids, table))
+        dout = torch.randn(5, 100, d, generator=g).to(dt).to(DEV)
+        dw = torch.zeros(V, d, device=DEV)
+        ops.embedding_bwd_(dout, ids, dw, padding_idx=3)
+        ref = torch.zeros(V, d, device=DEV)
+        keep = (ids != 3).reshape(-1)
+        ref.index_add_(0, ids.reshape(-1)[keep], dout.reshape(-1, d).float()[keep])
+        assert (dw - ref).abs().max() < 1e-4
+        assert float(dw[3].abs().max()) == 0.0
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    bad = ids.clone(); bad[1, 1] = V + 5
+    out = ops.embedding(table, bad, err_flag=err)
+    assert int(err.item()) == 1 and float(out[1, 1].abs().max()) == 0.0

@@ -805,6 +805,83 @@ extern "C" int vy_cast(const void* src, void* dst, int64_t n, int src_dtype, int
   return VY_OK;
 }
 
+// ---- token embedding: gather and its backward (reference: nn.Embedding in every model) ---------
+// fwd: out[m,:] = table[ids[m],:]; one wave per row, 16-byte chunks.  An id outside [0,V) is a
+// caller error the host cannot see without a sync: the row is written as zeros and `err` (device
+// int, optional) is set, the analogue of aten's device-side assert without killing the context.
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const T* __restrict__ table, int64_t ldt,
+                                                            const int64_t* __restrict__ ids, T* __restrict__ out,
+                                                            int64_t ldo, int64_t M, int d, int64_t V, int* err) {
+  constexpr int VEC = Chunk<T>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int64_t id = ids[m];
+  const bool bad = id < 0 || id >= V;
+  if (bad && err && lane == 0) *err = 1;
+  for (int c = lane; c * VEC < d; c += 64) {
+    float v[VEC];
+    if (bad) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    } else {
+      Chunk<T>::load(table + id * ldt + (int64_t)c * VEC, v);
+    }
+    Chunk<T>::store(out + m * ldo + (int64_t)c * VEC, v);
+  }
+}
+
+// bwd: dW[ids[m],:] += dOut[m,:] (fp32 atomics; rows of repeated ids collide, order not fixed);
+// the padding row receives no gradient, as in nn.Embedding(padding_idx=...)
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const T* __restrict__ dout, int64_t lddo,
+                                                            const int64_t* __restrict__ ids, float* __restrict__ dw,
+                                                            int64_t lddw, int64_t padding_idx, int64_t M, int d, int64_t V) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int64_t id = ids[m];
+  if (id == padding_idx || id < 0 || id >= V) return;
+  // lane-contiguous: one atomic instruction of the wave covers 64 consecutive floats (whole 128-byte
+  // lines at the L2 atomic units), not 64 scattered 32-byte pieces
+  float* row = dw + id * lddw;
+  const T* src = dout + m * lddo;
+  for (int c = lane; c < d; c += 64) atomicAdd(row + c, VyT<T>::ld(src + c));
+}
+
+extern "C" int vy_embedding_fwd(const void* table, int64_t ldt, const int64_t* ids, void* out, int64_t ldo,
+                                int64_t M, int64_t d, int64_t V, int32_t* err_flag, int dtype, void* stream) {
+  if (!table || !ids || !out || M <= 0 || d <= 0 || V <= 0) VY_FAIL(VY_ERR_ARG, "vy_embedding_fwd: bad arguments");
+  const int vec = dtype == VY_BF16 ? 8 : 4;
+  if (d % vec || ldt % vec || ldo % vec) VY_FAIL(VY_ERR_ARG, "vy_embedding_fwd: width and strides must be multiples of %d", vec);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)vy_cdiv(M, 4)), block(256);
+  if (dtype == VY_BF16)
+    hipLaunchKernelGGL(embedding_fwd_kernel<bf16>, grid, block, 0, st, (const bf16*)table, ldt, ids, (bf16*)out, ldo, M, (int)d, V, err_flag);
+  else if (dtype == VY_F32)
+    hipLaunchKernelGGL(embedding_fwd_kernel<float>, grid, block, 0, st, (const float*)table, ldt, ids, (float*)out, ldo, M, (int)d, V, err_flag);
+  else VY_FAIL(VY_ERR_ARG, "vy_embedding_fwd: bad dtype %d", dtype);
+  VY_CHECK_LAUNCH("vy_embedding_fwd");
+  return VY_OK;
+}
+
+extern "C" int vy_embedding_bwd(const void* dout, int64_t lddo, const int64_t* ids, float* dw, int64_t lddw,
+                                int64_t padding_idx, int64_t M, int64_t d, int64_t V, int dtype, void* stream) {
+  if (!dout || !ids || !dw || M <= 0 || d <= 0 || V <= 0) VY_FAIL(VY_ERR_ARG, "vy_embedding_bwd: bad arguments");
+  const int vec = dtype == VY_BF16 ? 8 : 4;
+  if (d % vec || lddo % vec) VY_FAIL(VY_ERR_ARG, "vy_embedding_bwd: width and strides must be multiples of %d", vec);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)vy_cdiv(M, 4)), block(256);
+  if (dtype == VY_BF16)
+    hipLaunchKernelGGL(embedding_bwd_kernel<bf16>, grid, block, 0, st, (const bf16*)dout, lddo, ids, dw, lddw, padding_idx, M, (int)d, V);
+  else if (dtype == VY_F32)
+    hipLaunchKernelGGL(embedding_bwd_kernel<float>, grid, block, 0, st, (const float*)dout, lddo, ids, dw, lddw, padding_idx, M, (int)d, V);
+  else VY_FAIL(VY_ERR_ARG, "vy_embedding_bwd: bad dtype %d", dtype);
+  VY_CHECK_LAUNCH("vy_embedding_bwd");
+  return VY_OK;
+}
+
 extern "C" int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t R, int64_t C,
                             int dtype, void* stream) {
   if (!in || !out || R <= 0 || C <= 0) VY_FAIL(VY_ERR_ARG, "vy_transpose: bad arguments");

@@ -67,6 +67,19 @@ class PositionMixin:
     # fp32 master weights with bf16 kernels: set by FlatTrainer (None = the parameters' dtype)
     compute_dtype = None
 
+    def _embed(self, emb: nn.Embedding, input_ids: torch.Tensor) -> torch.Tensor:
+        """Token embedding through vy_embedding_fwd/bwd (in the compute dtype when a trainer set one)."""
+        w = emb.weight
+        if not w.is_cuda:
+            return emb(input_ids)  # host-side use only (state-dict tooling); kernels need the GPU
+        from .. import ops
+        from ..layers.attention import _shadow
+        dt = self.compute_dtype or w.dtype
+        if torch.is_grad_enabled() and w.requires_grad:
+            from ..autograd_train import EmbeddingFn
+            return EmbeddingFn.apply(input_ids, w, emb.padding_idx, dt)
+        return ops.embedding(_shadow(w, dt), input_ids)
+
     def _cast(self, hidden_state: torch.Tensor) -> torch.Tensor:
         cd = self.compute_dtype
         return hidden_state if cd is None or hidden_state.dtype == cd else hidden_state.to(cd)

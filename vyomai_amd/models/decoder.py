@@ -101,7 +101,7 @@ class DecoderModel(nn.Module, PositionMixin):
                        use_cache: Optional[bool] = False, kv_cache=None, start_pos: Optional[int] = 0):
         """Everything of forward() up to the LM head -> (hidden_state, kv_cache)."""
         _bsz, seqlen = input_ids.shape
-        hidden_state = self.word_embeddings(input_ids)
+        hidden_state = self._embed(self.word_embeddings, input_ids)
         hidden_state, freqs = self._positions(hidden_state, start_pos, seqlen)
         mask = None
         if seqlen > 1:
@@ -171,7 +171,7 @@ class DecoderModel(nn.Module, PositionMixin):
                     from ..decode_plan import DecodePlan
                     plan = DecodePlan(self, kv_cache, bsz, self.compute_dtype or self.word_embeddings.weight.dtype,
                                       device)
-                hidden = self.word_embeddings(tokens[:, prev_pos:cur_pos])
+                hidden = self._embed(self.word_embeddings, tokens[:, prev_pos:cur_pos])
                 hidden, _ = self._positions(hidden, prev_pos, 1)
                 logits, _ = plan.step(hidden[:, 0, :].contiguous(), prev_pos)
                 next_token_logits = logits / temperature

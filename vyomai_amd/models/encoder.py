@@ -54,7 +54,7 @@ class EncoderModel(nn.Module, PositionMixin):
 
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> EncoderOutput:
         _, seqlen = input_ids.shape
-        hidden_state = self.word_embeddings(input_ids)
+        hidden_state = self._embed(self.word_embeddings, input_ids)
         hidden_state, freqs = self._positions(hidden_state, 0, seqlen)
         # the reference builds (1-mask)*finfo.min of shape (B,1,1,L) (:161-164); same information
         # as a key-padding descriptor

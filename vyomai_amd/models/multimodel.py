@@ -58,7 +58,7 @@ class VisionLanguageDecoderModel(nn.Module, PositionMixin):
                 encoder_hidden_state: Optional[torch.Tensor] = None, use_cache: Optional[bool] = False,
                 start_pos: Optional[int] = 0) -> DecoderOutput:
         bsz, _ = input_ids.shape
-        hidden_state = self.word_embeddings(input_ids)
+        hidden_state = self._embed(self.word_embeddings, input_ids)
         if start_pos == 0:  # the image vector is token 0 of the sequence (:163-169)
             hidden_state = torch.cat([encoder_hidden_state.to(hidden_state.dtype).unsqueeze(1), hidden_state], dim=1)
             if attention_mask is not None:

@@ -302,6 +302,29 @@ def xent_bwd_(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, 
          gscale.data_ptr(), count.data_ptr(), M, V, dtype_code(logits2d.dtype), _stream())
 
 
+def embedding(table: Tensor, ids: Tensor, err_flag: Optional[Tensor] = None) -> Tensor:
+    """out[..., :] = table[ids[...], :]  (vy_embedding_fwd).  table: (V, d) bf16/fp32; ids int64."""
+    _need_gpu(table, ids, err_flag)
+    assert ids.dtype == torch.long and table.dim() == 2 and table.stride(1) == 1
+    idc = ids.contiguous()
+    V, d = table.shape
+    out = torch.empty((*ids.shape, d), dtype=table.dtype, device=table.device)
+    call("vy_embedding_fwd", table.data_ptr(), table.stride(0), idc.data_ptr(), out.data_ptr(), d, idc.numel(), d, V,
+         _ptr(err_flag), dtype_code(table.dtype), _stream())
+    return out
+
+
+def embedding_bwd_(dout: Tensor, ids: Tensor, dw: Tensor, padding_idx: Optional[int]) -> None:
+    """dw[ids[m], :] += dout[m, :] in fp32, skipping padding_idx  (vy_embedding_bwd)."""
+    _need_gpu(dout, ids, dw)
+    d2 = _rows(dout)
+    idc = ids.contiguous()
+    assert dw.dtype == torch.float32 and dw.stride(1) == 1 and idc.numel() == d2.shape[0]
+    call("vy_embedding_bwd", d2.data_ptr(), d2.stride(0), idc.data_ptr(), dw.data_ptr(), dw.stride(0),
+         -1 if padding_idx is None else int(padding_idx), d2.shape[0], d2.shape[1], dw.shape[0],
+         dtype_code(dout.dtype), _stream())
+
+
 def xent_fused_(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, loss_sum: Tensor,
                 count: Tensor, gscale: Tensor) -> None:
     """One pass: lse / loss_sum as xent_fwd, then logits <- d loss / d logits in place (vy_xent_fused).
