@@ -229,6 +229,17 @@ int vy_embedding_bwd(const void* dout, int64_t lddo, const int64_t* ids, float* 
 int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t R, int64_t C,
                  int dtype, void* stream);
 
+/* Many transposes in one launch: descs_dev is a DEVICE array of n descriptors; tile0 is the running
+ * sum of ceil(R/32)*ceil(C/32) over the preceding descriptors, tiles_c = ceil(C/32), total_tiles the
+ * sum over all.  Used once per training step for every W^T the dgrad GEMMs read. */
+typedef struct vy_transpose_desc {
+  const void* in; void* out;      /* in: [R,C] row-major (ldin); out: [C,R] (ldout) */
+  int64_t ldin, ldout;
+  int32_t R, C, tile0, tiles_c;
+} vy_transpose_desc;              /* 48 bytes */
+int vy_transpose_batched(const vy_transpose_desc* descs_dev, int32_t n, int32_t total_tiles, int dtype,
+                         void* stream);
+
 /* y = x converted between fp32 and bf16 (n elements). src_dtype -> dst_dtype. */
 int vy_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 

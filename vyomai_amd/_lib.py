@@ -46,6 +46,7 @@ PROTOTYPES = {
     "vy_xent_fwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
     "vy_xent_bwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
     "vy_xent_fused": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    "vy_transpose_batched": [_p, _i, _i, _i, _p],
     "vy_embedding_fwd": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i, _p],
     "vy_embedding_bwd": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p],
     "vy_transpose": [_p, _i64, _p, _i64, _i64, _i64, _i, _p],

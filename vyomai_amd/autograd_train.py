@@ -12,6 +12,7 @@ Gradient delivery has two modes per parameter:
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -29,22 +30,73 @@ BF16 = torch.bfloat16
 WEIGHT_EPOCH = [0]
 
 
+class _WtRegistry:
+    """Every W^T the dgrad GEMMs read.  The first backward transposes each matrix as it meets it; from
+    then on ONE vy_transpose_batched launch per weight epoch refreshes all that were used in the
+    previous epoch (the per-matrix launches are latency-bound: ~8 us each, 50 per step).  Owners are
+    held weakly: a model that is dropped, or no longer trained, falls out of the batch."""
+
+    def __init__(self) -> None:
+        self.entries = []      # [weakref(owner), key_fn, src_fn, dst_view, last_used_epoch]
+        self.batch = None
+        self.epoch_done = -1
+
+    def register(self, owner, key_fn, src_fn, dst):
+        e = [weakref.ref(owner), key_fn, src_fn, dst, WEIGHT_EPOCH[0]]
+        self.entries.append(e)
+        return e
+
+    def refresh(self) -> None:
+        """Re-transpose the recently used matrices for the current WEIGHT_EPOCH (once per epoch)."""
+        ep = WEIGHT_EPOCH[0]
+        if self.epoch_done == ep:
+            return
+        self.epoch_done = ep
+        self.entries = [e for e in self.entries if e[0]() is not None]
+        live = [e for e in self.entries if e[4] >= ep - 1 and getattr(e[0](), "_vy_wt_key", None) != e[1](e[0]())]
+        if not live:
+            return
+        pairs = [(e[2](e[0]()), e[3]) for e in live]
+        keys = [(s_.data_ptr(), d_.data_ptr()) for s_, d_ in pairs]
+        if self.batch is None or self.batch.keys != keys:
+            self.batch = ops.TransposeBatch(pairs)
+        self.batch.run()
+        for e in live:
+            e[0]()._vy_wt_key = e[1](e[0]())
+
+
+_WT = _WtRegistry()
+
+
+def _wt_cached(owner, key_fn, src_fn) -> torch.Tensor:
+    """Shared body of _wt / _wt_packed: owner carries _vy_wt_key / _vy_wt_view / _vy_wt_entry.
+    key_fn / src_fn take the owner as their argument (the registry must not keep it alive)."""
+    view = getattr(owner, "_vy_wt_view", None)
+    key = key_fn(owner)
+    entry = getattr(owner, "_vy_wt_entry", None)
+    if entry is not None:
+        entry[4] = WEIGHT_EPOCH[0]
+    if view is not None and getattr(owner, "_vy_wt_key", None) == key:
+        return view
+    src = src_fn(owner)
+    if view is not None and view.dtype == src.dtype and view.device == src.device:
+        _WT.refresh()   # weights changed: all recently used matrices in one launch
+        if owner._vy_wt_key != key:
+            ops.transpose(src, view)   # not in the batch (first use after a pause, or an in-place edit)
+            owner._vy_wt_key = key
+        return view
+    N, K = src.shape
+    ld = (N + 7) // 8 * 8
+    view = torch.zeros((K, ld), dtype=src.dtype, device=src.device)[:, :N]  # pad columns stay zero
+    ops.transpose(src, view)
+    owner._vy_wt_view, owner._vy_wt_key = view, key
+    owner._vy_wt_entry = _WT.register(owner, key_fn, src_fn, view)
+    return view
+
+
 def _wt(param: torch.Tensor, dtype) -> torch.Tensor:
     """W^T ([K, N], row stride padded to 8) of a 2-D parameter in `dtype`, cached per version."""
-    cache = getattr(param, "_vy_wt", None)
-    src = _shadow(param, dtype)
-    key = (param._version, WEIGHT_EPOCH[0])
-    if cache is None or cache[0] != key or cache[1].dtype != dtype:
-        N, K = src.shape
-        ld = (N + 7) // 8 * 8
-        if cache is not None and cache[1].dtype == dtype and cache[1].device == src.device:
-            view = cache[1]  # same buffer: the pad columns were zeroed once and are never written
-        else:
-            view = torch.zeros((K, ld), dtype=dtype, device=src.device)[:, :N]
-        ops.transpose(src, view)
-        cache = (key, view)
-        param._vy_wt = cache
-    return cache[1]
+    return _wt_cached(param, lambda p: (p._version, WEIGHT_EPOCH[0], dtype), lambda p: _shadow(p, dtype))
 
 
 def _direct(p: Optional[torch.Tensor]) -> bool:
@@ -222,17 +274,8 @@ class SelfAttentionFn(torch.autograd.Function):
 
 def _wt_packed(mod, w, dtype):
     """W^T of the packed projection: keyed on the versions of the member parameters."""
-    members = mod._params()
-    key = tuple(p._version for p in members) + (WEIGHT_EPOCH[0],)
-    cache = getattr(mod, "_vy_wt_packed", None)
-    if cache is None or cache[0] != key or cache[1].dtype != dtype:
-        src = _shadow_packed(mod, w, dtype)
-        N, K = src.shape
-        buf = torch.empty((K, N), dtype=dtype, device=src.device)
-        ops.transpose(src, buf)
-        cache = (key, buf)
-        mod._vy_wt_packed = cache
-    return cache[1]
+    return _wt_cached(mod, lambda m: tuple(p._version for p in m._params()) + (WEIGHT_EPOCH[0], dtype),
+                      lambda m: _shadow_packed(m, m._packed()[0], dtype))
 
 
 def _shadow_packed(mod, w, dtype):

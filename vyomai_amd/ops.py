@@ -269,6 +269,36 @@ def transpose(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return out
 
 
+class TransposeBatch:
+    """Descriptor table for vy_transpose_batched: many (src [R,C] -> dst [C,R]) pairs, one launch."""
+
+    def __init__(self, pairs) -> None:
+        import ctypes as C
+        import numpy as np
+
+        class Desc(C.Structure):
+            _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ldin", C.c_int64), ("ldout", C.c_int64),
+                        ("R", C.c_int32), ("C", C.c_int32), ("tile0", C.c_int32), ("tiles_c", C.c_int32)]
+        assert C.sizeof(Desc) == 48
+        arr = (Desc * len(pairs))()
+        tile0 = 0
+        self.dtype = pairs[0][0].dtype
+        for i, (src, dst) in enumerate(pairs):
+            _need_gpu(src, dst)
+            R, Cc = src.shape
+            assert dst.shape == (Cc, R) and src.stride(1) == 1 and dst.stride(1) == 1 and src.dtype == self.dtype
+            tc = (Cc + 31) // 32
+            arr[i] = Desc(src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0), R, Cc, tile0, tc)
+            tile0 += tc * ((R + 31) // 32)
+        self.n, self.total = len(pairs), tile0
+        self.keys = [(s_.data_ptr(), d_.data_ptr()) for s_, d_ in pairs]
+        host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+        self.table = host.to(pairs[0][0].device)
+
+    def run(self) -> None:
+        call("vy_transpose_batched", self.table.data_ptr(), self.n, self.total, dtype_code(self.dtype), _stream())
+
+
 def cast(src: Tensor, dst: Tensor) -> Tensor:
     _need_gpu(src, dst)
     call("vy_cast", src.data_ptr(), dst.data_ptr(), src.numel(), dtype_code(src.dtype), dtype_code(dst.dtype), _stream())
