@@ -494,6 +494,123 @@ def generate(sd: SD, cfg: Cfg, ids: Tensor, max_new_tokens: int, pos_type="absol
 
 
 # ----------------------------------------------------------------------------
+# seq2seq: cross-attention + EncoderDecoderModel  (layers/attention.py:382-573,
+# models/encoder_decoder.py:33-391, generation_utils.py:54-125)
+# ----------------------------------------------------------------------------
+
+
+class OracleCrossCache:
+    """One cross-attention layer's cache: stored once, then returned unchanged
+    (StaticCache.update/get/__len__ :115-166 as the cross-attention uses them)."""
+
+    def __init__(self):
+        self.kv = None
+
+    def __len__(self):
+        return 0 if self.kv is None else self.kv[0].shape[2]
+
+
+def cross_attention(sd: SD, p: str, cfg: Cfg, x: Tensor, enc: Tensor, enc_mask: Optional[Tensor],
+                    gqa: bool, cache: Optional[OracleCrossCache] = None) -> Tensor:
+    """EncoderDecoderAttention{,Gqa}.forward: q from the decoder state, k/v from the encoder output
+    (computed once when a cache is attached), no RoPE, AttentionSelfOutput with the decoder state as
+    residual.  layers/attention.py:410-474 (vanilla), 512-573 (gqa)."""
+    dh = cfg.hidden_size // cfg.num_attention_heads
+    q = split_heads(linear(x, sd[p + "query.weight"], sd.get(p + "query.bias")), dh)
+    if cache is not None and len(cache) != 0:
+        k, v = cache.kv
+    else:
+        k = split_heads(linear(enc, sd[p + "key.weight"], sd.get(p + "key.bias")), dh)
+        v = split_heads(linear(enc, sd[p + "value.weight"], sd.get(p + "value.bias")), dh)
+        if cache is not None:
+            cache.kv = (k, v)
+    if gqa:
+        n_rep = cfg.num_attention_heads // cfg.num_key_value_heads
+        k, v = repeat_kv(k, n_rep), repeat_kv(v, n_rep)
+    o = merge_heads(sdpa(q, k, v, enc_mask))
+    return attention_self_output(sd, p + "out.", o, x, cfg.layer_norm_eps)
+
+
+def seq2seq_lm_head(sd: SD, p: str, cfg: Cfg, h: Tensor) -> Tensor:
+    """encoder_decoder.LMHead: dense -> GELU -> layer_norm -> vocab (bias = the tied `bias`
+    parameter).  models/encoder_decoder.py:86-110."""
+    x = gelu_erf(linear(h, sd[p + "dense.weight"], sd[p + "dense.bias"]))
+    x = layer_norm(x, sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], cfg.layer_norm_eps)
+    return linear(x, sd[p + "vocab.weight"], sd[p + "bias"])
+
+
+def seq2seq_decoder_forward(sd: SD, cfg: Cfg, input_ids: Tensor, attention_mask: Optional[Tensor],
+                            enc: Tensor, enc_mask: Tensor, pos_type: str = "absolute",
+                            attn_type: Optional[str] = None, self_cache=None, cross_caches=None,
+                            start_pos: int = 0, p: str = "decoder.") -> Tensor:
+    """Seq2SeqDecoderModel.forward -> hidden state.  models/encoder_decoder.py:156-212; layer :57-83:
+    self-attention -> cross-attention -> FeedForward whose residual is the LAYER INPUT."""
+    b, l = input_ids.shape
+    h = sd[p + "word_embeddings.weight"][input_ids]
+    freqs = None
+    sub = {k[len(p):]: v for k, v in sd.items() if k.startswith(p)}
+    pos = _position_info(sub, cfg, pos_type, start_pos, l)
+    if pos is not None:
+        h = h + pos.to(h.dtype)
+    else:
+        dh = cfg.hidden_size // cfg.num_attention_heads
+        freqs = rotary_angles(dh, cfg.max_position_embeddings)[:, start_pos:start_pos + l]
+    mask = None
+    if l > 1:
+        mask = decoder_additive_mask(b, l, attention_mask, start_pos, h.dtype)
+    gqa = attn_type == "gqa"
+    for i in range(cfg.num_hidden_layers):
+        lp = f"{p}all_layer.{i}."
+        a = self_attention(sd, lp + "attention.", cfg, h, mask, freqs, gqa, False, self_cache, i, start_pos)
+        c = cross_attention(sd, lp + "cross_attention.", cfg, a, enc, enc_mask, gqa,
+                            None if cross_caches is None else cross_caches[i])
+        h = feed_forward(sd, lp + "feed_forward.", cfg, c, h)
+    return h
+
+
+def encoder_decoder_forward(sd: SD, cfg_enc: Cfg, cfg_dec: Cfg, input_ids: Optional[Tensor],
+                            attention_mask: Optional[Tensor], decoder_input_ids: Tensor,
+                            decoder_attention_mask: Optional[Tensor] = None,
+                            encoder_output: Optional[Tensor] = None, enc_pos="absolute", enc_attn=None,
+                            dec_pos="absolute", dec_attn=None, self_cache=None, cross_caches=None,
+                            start_pos: int = 0):
+    """EncoderDecoderModel.forward -> (logits, encoder_output).  models/encoder_decoder.py:286-336."""
+    if encoder_output is None:
+        enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+        encoder_output = encoder_forward(enc_sd, cfg_enc, input_ids, attention_mask, enc_pos, enc_attn)
+    if attention_mask is None:
+        attention_mask = torch.ones(encoder_output.shape[:2])
+    enc_mask = padding_additive_mask(attention_mask, encoder_output.dtype)
+    h = seq2seq_decoder_forward(sd, cfg_dec, decoder_input_ids, decoder_attention_mask, encoder_output,
+                                enc_mask, dec_pos, dec_attn, self_cache, cross_caches, start_pos)
+    return seq2seq_lm_head(sd, "lm_head.", cfg_dec, h), encoder_output
+
+
+def generate_seq2seq(sd: SD, cfg_enc: Cfg, cfg_dec: Cfg, encoder_output: Tensor,
+                     encoder_attention_mask: Tensor, decoder_start: Tensor, max_new_tokens: int,
+                     dec_pos="absolute", dec_attn=None, use_cache: bool = False) -> Tensor:
+    """generation_utils.generate_seq2seq, greedy.  generation_utils.py:54-125."""
+    idx = decoder_start
+    nxt = idx
+    index = 0
+    self_cache = OracleDynamicCache(cfg_dec.num_hidden_layers) if use_cache else None
+    cross = [OracleCrossCache() for _ in range(cfg_dec.num_hidden_layers)] if use_cache else None
+    for _ in range(max_new_tokens):
+        if use_cache:
+            logits, _ = encoder_decoder_forward(sd, cfg_enc, cfg_dec, None, encoder_attention_mask, nxt, None,
+                                                encoder_output, dec_pos=dec_pos, dec_attn=dec_attn,
+                                                self_cache=self_cache, cross_caches=cross, start_pos=index)
+        else:
+            logits, _ = encoder_decoder_forward(sd, cfg_enc, cfg_dec, None, encoder_attention_mask, idx, None,
+                                                encoder_output, dec_pos=dec_pos, dec_attn=dec_attn)
+        probs = torch.softmax(logits[:, -1], dim=-1)
+        nxt = torch.topk(probs, k=1, dim=-1)[1]
+        idx = torch.cat((idx, nxt), dim=1)
+        index = idx.shape[1] - 1
+    return idx
+
+
+# ----------------------------------------------------------------------------
 # PaliGemma-shape blocks (Examples/paligemma.ipynb cells 9, 11-13).  The notebook has no importable
 # module; its class-definition cells are exec'd by tests/golden/make_golden.py to pin the layer
 # blocks (tests/golden/paligemma_blocks.npz).  The cached decode loop around them is unpinned.

@@ -190,6 +190,31 @@ def text_model_shapes(cfg, pos: str, attn_type, head: bool, p=""):
     return s
 
 
+def s2s_layer_shapes(cfg, kind: str, p=""):
+    """Seq2SeqDecoderLayer: self-attention, cross-attention (same parameter names), FeedForward."""
+    s = {p + "attention." + k: v for k, v in attn_shapes(cfg, kind).items()}
+    s.update({p + "cross_attention." + k: v for k, v in attn_shapes(cfg, kind).items()})
+    s.update(ffn_shapes(cfg, p + "feed_forward."))
+    return s
+
+
+def s2s_model_shapes(cfg, pos: str, attn_type):
+    """EncoderDecoderModel state_dict (models/encoder_decoder.py:261-284): encoder.*, decoder.*,
+    lm_head.{dense,layer_norm,vocab}.* and the tied lm_head.bias."""
+    d, v = cfg.hidden_size, cfg.vocab_size
+    kind = "gqa" if attn_type == "gqa" else "vanilla"
+    s = text_model_shapes(cfg, pos, attn_type, head=False, p="encoder.")
+    s["decoder.word_embeddings.weight"] = (v, d)
+    if pos == "absolute":
+        s["decoder.position_embeddings.pos_embeddings.weight"] = (cfg.max_position_embeddings, d)
+    for i in range(cfg.num_hidden_layers):
+        s.update(s2s_layer_shapes(cfg, kind, f"decoder.all_layer.{i}."))
+    s.update({"lm_head.bias": (v,), "lm_head.dense.weight": (d, d), "lm_head.dense.bias": (d,),
+              "lm_head.layer_norm.weight": (d,), "lm_head.layer_norm.bias": (d,),
+              "lm_head.vocab.weight": (v, d), "lm_head.vocab.bias": (v,)})
+    return s
+
+
 def vit_shapes(cfg, p=""):
     d = cfg.hidden_size
     ph, pw = cfg.patch_size

@@ -63,6 +63,14 @@ def test_state_dict_layout_matches_reference():
     # the vocabulary bias is ONE tied parameter under two keys (reference models/decoder.py:263-265)
     m = V.DecoderModel(cases.micro_cfg(), "rope", None)
     assert m.lm_head.bias is m.lm_head.decoder.bias
+    # seq2seq: encoder.*, decoder.* (attention + cross_attention + feed_forward), lm_head.vocab tied to
+    # lm_head.bias (reference models/encoder_decoder.py:86-99, 261-284)
+    for pos, at in (("absolute", None), ("rope", "gqa")):
+        cfg = cases.with_kv(cases.micro_cfg(), at)
+        s2s = V.EncoderDecoderModel.from_config(cfg, cfg, None, pos, at, pos, at)
+        want = cases.s2s_model_shapes(cfg, pos, at)
+        assert {k: tuple(t.shape) for k, t in s2s.state_dict().items()} == {k: tuple(v) for k, v in want.items()}
+        assert s2s.lm_head.bias is s2s.lm_head.vocab.bias
 
 
 def test_constructor_errors_match_reference():

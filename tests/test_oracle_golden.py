@@ -209,6 +209,68 @@ def test_gradients(golden, tag, at):
         close(got, want, 2e-5 * scale, what=n)
 
 
+@pytest.mark.parametrize("pos,at", [("absolute", None), ("sinusoidal", None), ("rope", None), ("rope", "gqa")])
+def test_seq2seq_models(golden, pos, at):
+    """EncoderDecoderModel (self-attention -> cross-attention -> FFN): logits with and without masks,
+    greedy generate_seq2seq token-exact in the no-cache / static / dynamic cache modes."""
+    g = golden("seq2seq")
+    cfg = cases.with_kv(cases.test_cfg(), at)
+    sd = sd_from(cases.s2s_model_shapes(cfg, pos, at))
+    c = O.Cfg.of(cfg)
+    ids, am = cases.reference_test_inputs()
+    ids, am = T(ids), T(am)
+    logits, enc = O.encoder_decoder_forward(sd, c, c, ids, am, ids, am, enc_pos=pos, enc_attn=at, dec_pos=pos,
+                                            dec_attn=at)
+    close(enc[:, :, ::4], g[f"s2s.{pos}.{at}.enc"], what="enc")
+    close(logits[:, :, ::97], g[f"s2s.{pos}.{at}.logits"], 5e-6, what="logits")
+    l2, _ = O.encoder_decoder_forward(sd, c, c, ids, None, ids[:, :9], None, enc_pos=pos, enc_attn=at,
+                                      dec_pos=pos, dec_attn=at)
+    close(l2[:, :, ::97], g[f"s2s.{pos}.{at}.logits.nomask"], 5e-6, what="logits.nomask")
+    enc_sd = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+    e1 = O.encoder_forward(enc_sd, c, ids[:1], am[:1], pos, at)
+    start = torch.tensor([[0]], dtype=torch.long)
+    t = O.generate_seq2seq(sd, c, c, e1, am[:1], start, 7, pos, at, use_cache=False)
+    assert np.array_equal(t.numpy(), g[f"s2s.{pos}.{at}.gen.nocache"])
+    t = O.generate_seq2seq(sd, c, c, e1, am[:1], start, 7, pos, at, use_cache=True)
+    assert np.array_equal(t.numpy(), g[f"s2s.{pos}.{at}.gen.static"])
+    assert np.array_equal(t.numpy(), g[f"s2s.{pos}.{at}.gen.dynamic"])
+
+
+@pytest.mark.parametrize("tag", ["micro", "wide"])
+@pytest.mark.parametrize("at", [None, "gqa"])
+def test_seq2seq_layer_gradients(golden, tag, at):
+    """Autograd through the oracle == autograd through the reference (one Seq2SeqDecoderLayer,
+    gradients w.r.t. the decoder state, the ENCODER output and every parameter)."""
+    g = golden("seq2seq")
+    cfg = cases.micro_cfg() if tag == "micro" else cases.wide_cfg()
+    c = O.Cfg.of(cfg)
+    B, L = cases.MODULE_BL[tag]
+    S = L + 5
+    d = cfg.hidden_size
+    dh = d // cfg.num_attention_heads
+    sd = sd_from(cases.s2s_layer_shapes(cfg, "gqa" if at == "gqa" else "vanilla"), f"{tag}.s2slayer.{at}.")
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = T(recipe.uniform(f"{tag}.s2s.x", (B, L, d))).requires_grad_(True)
+    enc = T(recipe.uniform(f"{tag}.s2s.enc", (B, S, d))).requires_grad_(True)
+    gout = T(recipe.uniform(f"{tag}.s2s.gout", (B, L, d)))
+    freqs = O.rotary_angles(dh, cfg.max_position_embeddings)[:, :L]
+    mask = T(cases.causal_additive(B, L, 0, cases.keypad(B, L)))
+    emask = T((1.0 - cases.keypad(B, S)[:, None, None, :].astype(np.float32)) * cases.FMIN)
+    a = O.self_attention(sd, "attention.", c, x, mask, freqs, at == "gqa")
+    cr = O.cross_attention(sd, "cross_attention.", c, a, enc, emask, at == "gqa")
+    y = O.feed_forward(sd, "feed_forward.", c, cr, x)
+    (y * gout).sum().backward()
+    close(y, g[f"grad.{tag}.{at}.y"], what="y")
+    close(x.grad, g[f"grad.{tag}.{at}.dx"], 2e-5, what="dx")
+    close(enc.grad, g[f"grad.{tag}.{at}.denc"], 2e-5, what="denc")
+    for n, p in sd.items():
+        want = g[f"grad.{tag}.{at}.d.{n}"]
+        got = p.grad if p.grad.numel() <= 4096 else cases.sub2(p.grad)
+        scale = max(1.0, float(np.abs(want).max()))
+        close(got, want, 2e-5 * scale, what=n)
+
+
 def test_paligemma_blocks(golden):
     """SigLIP and Gemma layers (true widths) vs the exec'd notebook cells."""
     g = golden("paligemma_blocks")

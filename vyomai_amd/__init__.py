@@ -9,4 +9,5 @@ from .models.encoder import EncoderModel, EncoderForMaskedLM  # noqa: F401
 from .models.decoder import DecoderModel  # noqa: F401
 from .models.vision_encoder import Vit  # noqa: F401
 from .models.multimodel import VisionLanguageModel  # noqa: F401
-from .generation_utils import generate, generate_multimodel  # noqa: F401
+from .models.encoder_decoder import EncoderDecoderModel  # noqa: F401
+from .generation_utils import generate, generate_multimodel, generate_seq2seq  # noqa: F401

@@ -118,3 +118,50 @@ def self_attention_block(mod, x, attention_mask, freqs, cache, cache_index, star
         o = ops.attention(q, k_all, v_all, **_mask_args(attention_mask, B, L, S, dev))
     return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
                                      aso.layernorm.bias, aso.layernorm.eps)
+
+
+def _split(x2: torch.Tensor, heads: int, dh: int) -> torch.Tensor:
+    """(B, L, heads*dh) projection output -> (B, heads, L, dh) strided view (no copy)."""
+    B, L, _ = x2.shape
+    return x2.view(B, L, heads, dh).permute(0, 2, 1, 3)
+
+
+def cross_attention_block(mod, x, enc, enc_mask, use_cache: bool):
+    """mod: layers.attention._CrossAttentionBase.  Returns LN(out(attn(q(x), k(enc), v(enc))) + x).
+    Reference layers/attention.py:410-474 / 512-573."""
+    B, L, _ = x.shape
+    h, hk, dh = mod.num_attention_heads, mod.num_key_value_heads, mod.head_dim
+    dt, dev = x.dtype, x.device
+    aso = mod.out
+    wq, bq = mod.query.weight, mod.query.bias
+    wk, bk = mod.key.weight, mod.key.bias
+    wv, bv = mod.value.weight, mod.value.bias
+    if _wants_grad(x, enc, wq, wk, wv, aso.dense.weight):
+        if use_cache:
+            raise VyomHipError("KV caching is an inference feature; call under torch.no_grad()")
+        from .autograd_train import CrossAttentionFn
+        o = CrossAttentionFn.apply(x, enc, mod, enc_mask, wq, bq, wk, bk, wv, bv)
+        return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
+                                         aso.layernorm.bias, aso.layernorm.eps)
+
+    def project():
+        k2 = ops.linear(enc, _shadow(wk, dt), _shadow(bk, dt))
+        v2 = ops.linear(enc, _shadow(wv, dt), _shadow(bv, dt))
+        return _split(k2, hk, dh), _split(v2, hk, dh)
+
+    q = _split(ops.linear(x, _shadow(wq, dt), _shadow(bq, dt)), h, dh)
+    if use_cache:
+        cache = getattr(mod, "cache", None)
+        if cache is None:
+            raise ValueError("use_cache is True please enable model._setup_cache() to use kv-cache")
+        if len(cache) == 0:   # first step: the encoder states are the same for the whole generation
+            k, v = cache.update(*project())
+        else:
+            k, v = cache.get()
+    else:
+        k, v = project()
+    S = k.shape[2]
+    o = ops.attention(q, k, v, **_mask_args(enc_mask, B, L, S, dev))
+    return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
+                                     aso.layernorm.bias, aso.layernorm.eps)
+

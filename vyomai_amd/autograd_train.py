@@ -272,6 +272,62 @@ class SelfAttentionFn(torch.autograd.Function):
         return (dx, None, None, None, None, *grads)
 
 
+class CrossAttentionFn(torch.autograd.Function):
+    """o = merge_heads(softmax(q k^T / sqrt(dh) + key-padding mask) v), q = x Wq^T + bq,
+    k/v = enc Wk/v^T + b: the encoder-decoder attention of the seq2seq decoder layer
+    (reference layers/attention.py:410-474, 512-573).  Gradients flow to the decoder state, to the
+    ENCODER output and to the three projections."""
+
+    @staticmethod
+    def forward(ctx, x, enc, mod, enc_mask, wq, bq, wk, bk, wv, bv):
+        _require_bf16(x)
+        B, L, _ = x.shape
+        S = enc.shape[1]
+        h, hk, dh = mod.num_attention_heads, mod.num_key_value_heads, mod.head_dim
+        dt, dev = x.dtype, x.device
+        if enc_mask is not None and not isinstance(enc_mask, AttnMask):
+            raise VyomHipError("training needs a mask descriptor (AttnMask): dense additive masks have no "
+                               "backward kernel")
+        q2 = ops.linear(x, _shadow(wq, dt), _shadow(bq, dt))
+        k2 = ops.linear(enc, _shadow(wk, dt), _shadow(bk, dt))
+        v2 = ops.linear(enc, _shadow(wv, dt), _shadow(bv, dt))
+        kp = None
+        if enc_mask is not None:
+            if enc_mask.causal:
+                raise VyomHipError("cross-attention takes a key-padding mask, not a causal one")
+            kp = enc_mask.keypad
+            if kp is not None:
+                kp = kp[:, :S].contiguous() if kp.shape[1] != S else kp
+        lse = torch.empty((B, h, L), dtype=torch.float32, device=dev)
+        o = ops.attention(_heads(q2, h, dh), _heads(k2, hk, dh), _heads(v2, hk, dh), causal=False, keypad=kp, lse=lse)
+        ctx.save_for_backward(x, enc, q2, k2, v2, o, lse)
+        ctx.meta = (mod, kp, (wq, bq, wk, bk, wv, bv))
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        x, enc, q2, k2, v2, o, lse = ctx.saved_tensors
+        mod, kp, (wq, bq, wk, bk, wv, bv) = ctx.meta
+        h, hk, dh = mod.num_attention_heads, mod.num_key_value_heads, mod.head_dim
+        dt = x.dtype
+        do = do.contiguous()
+        dq2, dk2, dv2 = torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
+        ops.attention_bwd(_heads(q2, h, dh), _heads(k2, hk, dh), _heads(v2, hk, dh), o, do, lse,
+                          _heads(dq2, h, dh), _heads(dk2, hk, dh), _heads(dv2, hk, dh), causal=False, keypad=kp)
+        dx = ops.linear_dgrad(dq2, _wt(wq, dt))
+        denc = ops.linear_dgrad(dk2, _wt(wk, dt))
+        denc = ops.linear_dgrad(dv2, _wt(wv, dt), add_to=denc)
+        dwq, dbq = _wgrad(dq2, x, wq, bq)
+        dwk, dbk = _wgrad(dk2, enc, wk, bk)
+        dwv, dbv = _wgrad(dv2, enc, wv, bv)
+        return dx, denc, None, None, dwq, dbq, dwk, dbk, dwv, dbv
+
+
+def _heads(x2: torch.Tensor, heads: int, dh: int) -> torch.Tensor:
+    B, L, _ = x2.shape
+    return x2.view(B, L, heads, dh).permute(0, 2, 1, 3)
+
+
 def _wt_packed(mod, w, dtype):
     """W^T of the packed projection: keyed on the versions of the member parameters."""
     return _wt_cached(mod, lambda m: tuple(p._version for p in m._params()) + (WEIGHT_EPOCH[0], dtype),

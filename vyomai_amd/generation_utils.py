@@ -53,3 +53,26 @@ def generate_multimodel(model: nn.Module, encoder_output: torch.Tensor, encoder_
         idx = torch.cat((idx, nxt), dim=1)
         index = idx.size(1)
     return idx
+
+
+@torch.no_grad()
+def generate_seq2seq(model: nn.Module, encoder_output: torch.Tensor, encoder_attention_mask: torch.Tensor,
+                     decoder_start: torch.Tensor, max_new_tokens: Optional[int] = 5,
+                     temperature: Optional[float] = 1.0, do_sample: Optional[bool] = False,
+                     top_k: Optional[int] = 10, use_cache: Optional[bool] = False) -> torch.Tensor:
+    """Reference :54-125.  With a cache the first call feeds the whole decoder start (start_pos 0),
+    later calls only the newest token with start_pos = tokens already cached."""
+    idx = nxt = decoder_start
+    index = 0
+    for _ in range(max_new_tokens):
+        if use_cache:
+            logits = model(encoder_output=encoder_output, attention_mask=encoder_attention_mask,
+                           decoder_input_ids=nxt, use_cache=use_cache, start_pos=index).logits
+        else:
+            logits = model(encoder_output=encoder_output, attention_mask=encoder_attention_mask,
+                           decoder_input_ids=idx, use_cache=use_cache).logits
+        nxt = _pick(logits[:, -1], temperature, do_sample)
+        idx = torch.cat((idx, nxt), dim=1)
+        index = idx.size(1) - 1
+    return idx
+

@@ -244,3 +244,37 @@ class VisionAttention(_SelfAttentionBase):
 
     def forward(self, hidden_state, attention_mask, freqs=None) -> torch.Tensor:
         return self._attend(hidden_state, attention_mask, freqs)
+
+
+class _CrossAttentionBase(_SelfAttentionBase):
+    """Shared body of the encoder-decoder (cross) attention variants (not a reference class)."""
+
+    def forward(self, hidden_state: torch.Tensor, encoder_hidden_state: torch.Tensor, encoder_attention_mask,
+                freqs=None, use_cache: Optional[bool] = False) -> torch.Tensor:
+        """q from `hidden_state`, k/v from `encoder_hidden_state` (computed once and kept in
+        ``self.cache`` when use_cache), no RoPE (the reference leaves it commented out), then
+        AttentionSelfOutput with `hidden_state` as residual.  `encoder_attention_mask` is a key-padding
+        descriptor (AttnMask) or the reference's additive (B,1,1,S) tensor."""
+        from ..autograd import cross_attention_block
+        _check_dropout(self, self.out.dropout.p)
+        if not hidden_state.is_cuda:
+            raise VyomHipError("vyomai_amd attention runs on MI355X only (got a CPU tensor; there is "
+                               "no CPU fallback -- the CPU restatement lives in oracle/ for tests)")
+        return cross_attention_block(self, hidden_state, encoder_hidden_state, encoder_attention_mask, bool(use_cache))
+
+
+class EncoderDecoderAttention(_CrossAttentionBase):
+    """Reference layers/attention.py:382-474."""
+
+    def __init__(self, config, layer_idx: int) -> None:
+        super().__init__()
+        self._setup(config, layer_idx, None, fused_qkv=False)
+
+
+class EncoderDecoderAttentionGqa(_CrossAttentionBase):
+    """Reference layers/attention.py:477-573 (K/V projections of num_key_value_heads heads, default 4)."""
+
+    def __init__(self, config, layer_idx: int) -> None:
+        super().__init__()
+        self._setup(config, layer_idx, getattr(config, "num_key_value_heads", 4), fused_qkv=False)
+

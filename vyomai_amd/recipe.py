@@ -63,6 +63,8 @@ def param_value(name: str, shape: Tuple[int, ...]) -> np.ndarray:
     # LMHead ties ``decoder.bias`` to ``bias`` (reference models/decoder.py:263-265):
     # both state_dict keys must resolve to one value.
     name = name.replace("lm_head.decoder.bias", "lm_head.bias")
+    # the seq2seq LMHead ties ``vocab.bias`` to ``bias`` the same way (models/encoder_decoder.py:97-99)
+    name = name.replace("lm_head.vocab.bias", "lm_head.bias")
     leaf = name.rsplit(".", 1)[-1]
     is_ln = ("layernorm" in name) or ("layer_norm" in name) or ("norm." in name)
     if is_ln and leaf == "weight":
