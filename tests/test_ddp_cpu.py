@@ -86,3 +86,27 @@ def test_bucket_reducer_gloo_world2():
         p.join(100)
         assert p.exitcode == 0
     assert q.get(timeout=5) == "ok"
+
+
+def test_bucket_waits_for_every_parameter_once():
+    """A parameter may report readiness twice in one backward (the kernel-side notification AND the
+    autograd post-accumulate hook): it must count once, or a bucket is reduced -- and, with the
+    overlapped optimizer, stepped -- before its last gradients exist."""
+    from vyomai_amd.training import BucketReducer, FlatArena
+    torch.manual_seed(0)
+    model = Tiny()
+    arena = FlatArena(model, shadow_dtype=None)
+    red = BucketReducer(arena, bucket_bytes=1 << 30)   # one bucket
+    assert len(red.buckets) == 1
+    fired = []
+    red.on_bucket = lambda b, work: fired.append(b)
+    red.reset()
+    params = list(model.parameters())
+    for p in params[:-1]:
+        red.mark_ready(p)
+        red.mark_ready(p)          # duplicate report
+    assert fired == [], "bucket went out before its last parameter was ready"
+    red.mark_ready(params[-1])
+    assert fired == [0]
+    red.mark_ready(params[-1])     # late duplicate: ignored
+    assert fired == [0]

@@ -23,6 +23,8 @@ fused optimizer step needs the GPU.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -163,6 +165,10 @@ class BucketReducer:
         self._launched = [False] * len(self.buckets)
         self._works: List = []
         self.launch_order: List[int] = []
+        self._seen: set = set()
+        # called as on_bucket(b, work) when bucket b's gradients are final on this rank and its
+        # all-reduce (work, None when world == 1) has been enqueued -- the trainer steps the bucket
+        self.on_bucket = None
         for p in arena.params:
             p._vy_ready = self.mark_ready
             # gradients produced by torch autograd itself (embedding tables) arrive through the tape
@@ -176,11 +182,17 @@ class BucketReducer:
         self._launched = [False] * len(self.buckets)
         self._works = []
         self.launch_order = []
+        self._seen = set()
 
     def mark_ready(self, p) -> None:
         b = self.bucket_of[id(p)]
         if self._launched[b]:
             return
+        if id(p) in self._seen:   # a parameter reports once per backward, however many ops fed it
+            if os.environ.get("VY_DEBUG_READY"):
+                print("double ready:", [n for n, q in self.arena.items if q is p])
+            return
+        self._seen.add(id(p))
         self._pending[b] += 1
         if self._pending[b] >= self.expect[b]:
             self._launch(b)
@@ -188,11 +200,14 @@ class BucketReducer:
     def _launch(self, b: int) -> None:
         self._launched[b] = True
         self.launch_order.append(b)
-        if self.world == 1:
-            return
-        s, e = self.buckets[b]
-        view = self.arena.grad[s:e]
-        self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        work = None
+        if self.world > 1:
+            s, e = self.buckets[b]
+            view = self.arena.grad[s:e]
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._works.append(work)
+        if self.on_bucket is not None:
+            self.on_bucket(b, work)
 
     def finish(self) -> float:
         """Flush buckets whose parameters never got a gradient, wait for the exchange and return
@@ -211,7 +226,7 @@ class FlatTrainer:
 
     def __init__(self, model: nn.Module, lr: float = 5e-5, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 0.01, compute_dtype: torch.dtype = torch.bfloat16,
-                 process_group=None, bucket_bytes: int = 64 << 20):
+                 process_group=None, bucket_bytes: int = 64 << 20, overlap_optimizer: bool = True):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         for m in model.modules():
@@ -222,22 +237,57 @@ class FlatTrainer:
         self.v = torch.zeros_like(self.arena.master)
         self.reducer = BucketReducer(self.arena, process_group, bucket_bytes)
         self.step_count = 0
+        # AdamW is an HBM stream (30 B/param), the backward GEMMs are not HBM-bound: each gradient
+        # bucket is stepped on a side stream as soon as it is final (and reduced), under the rest of
+        # backward.  A bucket is final only when every layer that owns a parameter in it has finished
+        # its backward, so nothing that still runs reads the weights being rewritten.
+        if os.environ.get("VY_OVERLAP_OPT") == "0":   # A/B knob
+            overlap_optimizer = False
+        self._side = torch.cuda.Stream() if (overlap_optimizer and self.arena.master.is_cuda) else None
+        self._stepped: set = set()
+        self._scale = (1.0 / self.reducer.world) if (self.reducer.average and self.reducer.world > 1) else 1.0
+        if self._side is not None:
+            self.reducer.on_bucket = self._bucket_final
 
     def zero_grad(self) -> None:
         self.arena.zero_grad()
         self.reducer.reset()
+        self._stepped = set()
 
     def backward(self, loss: torch.Tensor) -> None:
         loss.backward()
 
-    def optimizer_step(self) -> None:
+    def _adamw(self, lo: int, hi: int, step: int) -> None:
         from . import ops
+        a = self.arena
+        ops.adamw_step(a.master[lo:hi], a.grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
+                       None if a.shadow is None else a.shadow[lo:hi], self.lr, self.betas[0], self.betas[1],
+                       self.eps, self.weight_decay, step, self._scale)
+
+    def _bucket_final(self, b: int, work) -> None:
+        """Reducer callback (during backward): step bucket b on the side stream."""
+        lo, hi = self.reducer.buckets[b]
+        ev = torch.cuda.current_stream().record_event()   # after the kernels that wrote its gradients
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            if work is not None:
+                work.wait()                                # the side stream waits for the all-reduce
+            self._adamw(lo, hi, self.step_count + 1)
+        self._stepped.add(b)
+
+    def optimizer_step(self) -> None:
         from .autograd_train import WEIGHT_EPOCH
 
-        scale = self.reducer.finish()
+        scale = self.reducer.finish()   # flushes buckets without gradients (their callbacks run here too)
+        assert abs(scale - self._scale) < 1e-12
         self.step_count += 1
-        ops.adamw_step(self.arena.master, self.arena.grad, self.m, self.v, self.arena.shadow, self.lr,
-                       self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, scale)
+        if self._side is None:
+            self._adamw(0, self.arena.numel, self.step_count)
+        else:
+            for b, (lo, hi) in enumerate(self.reducer.buckets):
+                if b not in self._stepped:
+                    self._adamw(lo, hi, self.step_count)
+            torch.cuda.current_stream().wait_stream(self._side)
         WEIGHT_EPOCH[0] += 1
 
     def train_step(self, loss_fn: Callable[[], torch.Tensor]) -> torch.Tensor:
