@@ -230,7 +230,7 @@ int vy_transpose(const void* in, int64_t ldin, void* out, int64_t ldout, int64_t
                  int dtype, void* stream);
 
 /* Many transposes in one launch: descs_dev is a DEVICE array of n descriptors; tile0 is the running
- * sum of ceil(R/32)*ceil(C/32) over the preceding descriptors, tiles_c = ceil(C/32), total_tiles the
+ * sum of ceil(R/64)*ceil(C/64) over the preceding descriptors, tiles_c = ceil(C/64), total_tiles the
  * sum over all.  Used once per training step for every W^T the dgrad GEMMs read. */
 typedef struct vy_transpose_desc {
   const void* in; void* out;      /* in: [R,C] row-major (ldin); out: [C,R] (ldout) */

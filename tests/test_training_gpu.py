@@ -186,3 +186,19 @@ def test_embedding_kernels():
     bad = ids.clone(); bad[1, 1] = V + 5
     out = ops.embedding(table, bad, err_flag=err)
     assert int(err.item()) == 1 and float(out[1, 1].abs().max()) == 0.0
+
+
+def test_transpose_batched():
+    """vy_transpose_batched: several matrices (odd sizes, padded row strides) in one launch."""
+    from vyomai_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for dt in (BF, torch.float32):
+        pairs = []
+        for R, C in ((768, 768), (2304, 768), (1031, 768), (70, 200), (3, 5)):
+            src = torch.randn(R, C, generator=g).to(dt).to(DEV)
+            ld = (R + 7) // 8 * 8
+            dst = torch.full((C, ld), 7.0, dtype=dt, device=DEV)[:, :R]
+            pairs.append((src, dst))
+        ops.TransposeBatch(pairs).run()
+        for src, dst in pairs:
+            assert torch.equal(dst, src.t()), (src.shape, dt)

@@ -378,7 +378,12 @@ __global__ void transpose_kernel(const T* __restrict__ in, int64_t ldin, T* __re
 // a 1-5 MB matrix, 50 of them per training step): block -> matrix by bisection of the tile prefix
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const vy_transpose_desc* __restrict__ descs, int n) {
-  __shared__ T tile[32][33];
+  // 64 x 64 tile (tile0 / tiles_c count 64-wide tiles): 16-byte loads along the input rows, 16-byte
+  // stores along the output rows, the transposition through LDS (row pitch 66 elements: the eight
+  // column reads of a store hit different banks)
+  constexpr int VEC = 16 / (int)sizeof(T);   // 8 (bf16) or 4 (fp32)
+  constexpr int CPRW = 64 / VEC;              // 16-byte chunks per 64-element row
+  __shared__ T tile[64][66];
   int lo = 0, hi = n - 1;
   const int b = blockIdx.x;
   while (lo < hi) {
@@ -387,18 +392,42 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const vy_transpo
   }
   const vy_transpose_desc d = descs[lo];
   const int t = b - d.tile0;
-  const int c0 = (t % d.tiles_c) * 32, r0 = (t / d.tiles_c) * 32;
+  const int c0 = (t % d.tiles_c) * 64, r0 = (t / d.tiles_c) * 64;
   const T* in = (const T*)d.in;
   T* out = (T*)d.out;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + tx;
-    if (r < d.R && c < d.C) tile[i][tx] = in[(int64_t)r * d.ldin + c];
+  const bool vec_in = (d.ldin % VEC) == 0 && ((uintptr_t)in % 16) == 0;
+  const bool vec_out = (d.ldout % VEC) == 0 && ((uintptr_t)out % 16) == 0;
+  for (int c = threadIdx.x; c < 64 * CPRW; c += 256) {
+    const int r = c / CPRW, cc = (c % CPRW) * VEC;
+    const int gr = r0 + r, gc = c0 + cc;
+    if (gr >= d.R) continue;
+    if (vec_in && gc + VEC <= d.C) {
+      typedef typename Chunk<T>::Raw Raw;
+      const Raw raw = *reinterpret_cast<const Raw*>(in + (int64_t)gr * d.ldin + gc);
+      const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) tile[r][cc + k] = e[k];
+    } else {
+      for (int k = 0; k < VEC; ++k)
+        if (gc + k < d.C) tile[r][cc + k] = in[(int64_t)gr * d.ldin + gc + k];
+    }
   }
   __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + tx;
-    if (r < d.R && c < d.C) out[(int64_t)c * d.ldout + r] = tile[tx][i];
+  for (int c = threadIdx.x; c < 64 * CPRW; c += 256) {
+    const int oc = c / CPRW, rr = (c % CPRW) * VEC;   // output row = input column c0 + oc
+    const int gc = c0 + oc, gr = r0 + rr;
+    if (gc >= d.C) continue;
+    if (vec_out && gr + VEC <= d.R) {
+      typedef typename Chunk<T>::Raw Raw;
+      Raw raw;
+      T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) e[k] = tile[rr + k][oc];
+      *reinterpret_cast<Raw*>(out + (int64_t)gc * d.ldout + gr) = raw;
+    } else {
+      for (int k = 0; k < VEC; ++k)
+        if (gr + k < d.R) out[(int64_t)gc * d.ldout + gr + k] = tile[rr + k][oc];
+    }
   }
 }
 

@@ -287,9 +287,9 @@ class TransposeBatch:
             _need_gpu(src, dst)
             R, Cc = src.shape
             assert dst.shape == (Cc, R) and src.stride(1) == 1 and dst.stride(1) == 1 and src.dtype == self.dtype
-            tc = (Cc + 31) // 32
+            tc = (Cc + 63) // 64
             arr[i] = Desc(src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0), R, Cc, tile0, tc)
-            tile0 += tc * ((R + 31) // 32)
+            tile0 += tc * ((R + 63) // 64)
         self.n, self.total = len(pairs), tile0
         self.keys = [(s_.data_ptr(), d_.data_ptr()) for s_, d_ in pairs]
         host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
