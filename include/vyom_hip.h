@@ -147,12 +147,15 @@ int vy_rope_fwd(void* x, int64_t sb, int64_t sh, int64_t sl, const float* cos_ta
  * author's own fused notebook (Examples/vyom-ai-decoder-fused.ipynb cells 2-7, 11).
  * ------------------------------------------------------------------------------------------ */
 
-/* dX[M,K] = dY[M,N] . W[N,K]  (+ add_to[M,K]); optional GELU backward: when `pre` is given the
- * result is multiplied by gelu'(pre[M,K]) (pre = saved pre-activation of the consumer of dX).
- * wt is W transposed, i.e. stored [K,N] row-major (the trainer keeps both copies). */
+/* dX[M,K] = dY[M,N] . W[N,K]  (+ add_to[M,K] + add_to2[M,K]); optional GELU backward: when `pre` is
+ * given the result is multiplied by gelu'(pre[M,K]) (pre = saved pre-activation of the consumer of
+ * dX).  wt is W transposed, i.e. stored [K,N] row-major (the trainer keeps both copies).  The two
+ * addends are the residual-path gradients a layer input collects besides the QKV projection's
+ * (add_to2 needs add_to). */
 int vy_linear_dgrad(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const void* pre,
-                    int64_t ldpre, int act, const void* add_to, int64_t ldadd, void* dx,
-                    int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype, void* stream);
+                    int64_t ldpre, int act, const void* add_to, int64_t ldadd, const void* add_to2,
+                    int64_t ldadd2, void* dx, int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype,
+                    void* stream);
 
 /* dW[N,K] (fp32, accumulate when beta != 0) = alpha * dY[M,N]^T . X[M,K];  db[N] (fp32) likewise
  * alpha * colsum(dY).  alpha_dev: optional DEVICE fp32 scalar (NULL = 1), e.g. the upstream

@@ -34,7 +34,7 @@ PROTOTYPES = {
     "vy_rmsnorm_fwd": [_p, _i64, _p, _p, _i64, _i64, _i64, _f, _f, _i, _p],
     "vy_gated_act_fwd": [_p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
     "vy_rope_fwd": [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i, _i64, _i, _i, _i, _p],
-    "vy_linear_dgrad": [_p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _i64, _i64, _i64, _i, _p],
+    "vy_linear_dgrad": [_p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i, _p],
     "vy_linear_wgrad": [_p, _i64, _p, _i64, _p, _i64, _p, _f, _p, _i64, _i64, _i64, _i, _p],
     "vy_layernorm_bwd": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _p, _f, _p, _i64, _i64, _i, _p],
     "vy_attn_bwd": [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,

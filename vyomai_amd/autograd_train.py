@@ -135,6 +135,20 @@ def _ln_bwd(dy, x, ln_w, ln_b, mean, rstd):
     return dx, dg.to(ln_w.dtype), db.to(ln_b.dtype)
 
 
+def _defer_list(t: torch.Tensor):
+    """The list a layer attached to its input tensor (`_vy_defer`): backward functions that produce a
+    residual-path gradient for that tensor append it there instead of returning it, and the
+    self-attention backward -- which autograd necessarily runs after them -- adds them in its dgrad
+    epilogue.  None when the layer did not opt in."""
+    return getattr(t, "_vy_defer", None) if t is not None else None
+
+
+def defer_residual_grads(x: torch.Tensor) -> None:
+    """Called by a post-LN transformer layer on its input (training only): see _defer_list."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        x._vy_defer = []
+
+
 def _require_bf16(x: torch.Tensor) -> None:
     if x.dtype != BF16:
         raise VyomHipError("training kernels are bf16 (fp32 master weights): feed bf16 activations, e.g. via "
@@ -175,6 +189,7 @@ class LinearResidualLayerNormFn(torch.autograd.Function):
         y, mean, rstd = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
         ctx.save_for_backward(x, s, mean, rstd)
         ctx.params = (w, b, ln_w, ln_b)
+        ctx.defer = _defer_list(residual)
         return y
 
     @staticmethod
@@ -185,6 +200,9 @@ class LinearResidualLayerNormFn(torch.autograd.Function):
         ds, dg, dbt = _ln_bwd(dy, s, ln_w, ln_b, mean, rstd)
         dx = ops.linear_dgrad(ds, _wt(w, x.dtype))
         dw, db = _wgrad(ds, x, w, b)
+        if ctx.defer is not None:      # the residual gradient rides to the QKV dgrad epilogue
+            ctx.defer.append(ds)
+            ds = None
         return dx, ds, dw, db, dg, dbt, None
 
 
@@ -203,6 +221,7 @@ class FfnBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, pre, hmid, s, mean, rstd)
         ctx.params = (w1, b1, w2, b2, ln_w, ln_b)
         ctx.act = act
+        ctx.defer = _defer_list(residual) if residual is not x else None
         return y
 
     @staticmethod
@@ -216,6 +235,9 @@ class FfnBlockFn(torch.autograd.Function):
         dw2, db2 = _wgrad(ds, hmid, w2, b2)
         dx = ops.linear_dgrad(dpre, _wt(w1, dt))
         dw1, db1 = _wgrad(dpre, x, w1, b1)
+        if ctx.defer is not None:
+            ctx.defer.append(ds)
+            ds = None
         return dx, ds, dw1, db1, dw2, db2, dg, dbt, None, None
 
 
@@ -248,6 +270,7 @@ class SelfAttentionFn(torch.autograd.Function):
         o = ops.attention(q, k, v, causal=causal, start_pos=sp, keypad=kp, lse=lse)
         ctx.save_for_backward(x, q, k, v, o, lse)
         ctx.meta = (mod, causal, kp, sp, cos, sin, pos0, params)
+        ctx.defer = _defer_list(x)
         return o
 
     @staticmethod
@@ -267,7 +290,19 @@ class SelfAttentionFn(torch.autograd.Function):
         ops.attention_bwd(q, k, v, o, do, lse, dq, dk, dv, causal=causal, start_pos=sp, keypad=kp,
                           cos=cos, sin=sin, rope_pos0=pos0)
         w, b = mod._packed()
-        dx = ops.linear_dgrad(packed, _wt_packed(mod, w, dt))
+        # the layer input's other gradient contributions (residual paths of this layer's out-projection
+        # and feed-forward, deferred by their backward) are added in this GEMM's epilogue
+        adds = ctx.defer if ctx.defer is not None else []
+        extra = None
+        for t in adds[2:]:
+            extra = t if extra is None else extra + t
+        a1 = adds[0] if len(adds) > 0 else None
+        a2 = adds[1] if len(adds) > 1 else None
+        if extra is not None:
+            a2 = a2 + extra
+        dx = ops.linear_dgrad(packed, _wt_packed(mod, w, dt), add_to=a1, add_to2=a2)
+        if ctx.defer is not None:
+            ctx.defer.clear()
         grads = _packed_wgrad(mod, packed, x, w, b, params)
         return (dx, None, None, None, None, *grads)
 

@@ -58,6 +58,7 @@ template <typename T>
 struct EpiPlain {
   const T* bias;
   const T* residual; int64_t ldr;
+  const T* residual2; int64_t ldr2;  // second addend (dgrad: the two residual-path gradients of a layer)
   const T* gradpre;  int64_t ldg;
   T* y;   int64_t ldy;
   T* pre; // same ld as y
@@ -85,6 +86,9 @@ __device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[
     if (e.residual) { float r[4]; Quad<T>::load(e.residual + m * e.ldr + n, r);
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += r[i]; }
+    if (e.residual2) { float r[4]; Quad<T>::load(e.residual2 + m * e.ldr2 + n, r);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += r[i]; }
     Quad<T>::store(e.y + m * e.ldy + n, v);
   } else {
 #pragma unroll
@@ -96,6 +100,7 @@ __device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[
       if constexpr (!GRAD) x = vy_act_fwd<ACT>(x);
       else if (e.gradpre) x *= vy_act_grad<ACT>(VyT<T>::ld(e.gradpre + m * e.ldg + n + i));
       if (e.residual) x += VyT<T>::ld(e.residual + m * e.ldr + n + i);
+      if (e.residual2) x += VyT<T>::ld(e.residual2 + m * e.ldr2 + n + i);
       VyT<T>::st(e.y + m * e.ldy + n + i, x);
     }
   }
@@ -259,6 +264,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
             }
+            if (ep.residual2) {
+              const bf16x8 r = *reinterpret_cast<const bf16x8*>(ep.residual2 + m * ep.ldr2 + n);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+            }
           }
           bf16x8 o;
 #pragma unroll
@@ -272,6 +282,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
                 if (ep.gradpre) x *= vy_act_grad_fast<ACT>((float)ep.gradpre[m * ep.ldg + n + e]);
               }
               if (ep.residual) x += (float)ep.residual[m * ep.ldr + n + e];
+              if (ep.residual2) x += (float)ep.residual2[m * ep.ldr2 + n + e];
             }
             dst[m * ep.ldy + n + e] = (bf16)x;
           }
@@ -1236,16 +1247,19 @@ template <typename T>
 int linear_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                 const void* residual, int64_t ldr, const void* gradpre, int64_t ldg, void* y,
                 int64_t ldy, void* pre_out, int64_t M, int64_t N, int64_t K, int act, bool grad,
-                hipStream_t st, const char* who) {
+                hipStream_t st, const char* who, const void* residual2 = nullptr, int64_t ldr2 = 0) {
   if (int rc = check_operands<T>(who, x, ldx, w, ldw, M, N, K)) return rc;
   if (!y) VY_FAIL(VY_ERR_ARG, "%s: null output", who);
   if (ldy < N) VY_FAIL(VY_ERR_ARG, "%s: ldy < N", who);
   EpiPlain<T> ep;
   ep.bias = (const T*)bias; ep.residual = (const T*)residual; ep.ldr = ldr;
+  ep.residual2 = (const T*)residual2; ep.ldr2 = ldr2;
+  if (residual2 && !residual) VY_FAIL(VY_ERR_ARG, "%s: add_to2 without add_to", who);
   ep.gradpre = (const T*)gradpre; ep.ldg = ldg; ep.y = (T*)y; ep.ldy = ldy; ep.pre = (T*)pre_out;
   const int ve = 16 / (int)sizeof(T);  // elements per 16-byte access (bf16: 8, f32 quads: 4)
   ep.vec_ok = (ldy % ve == 0) && aligned_to(y, 16) && (!bias || aligned_to(bias, 4 * sizeof(T))) &&
               (!residual || (ldr % ve == 0 && aligned_to(residual, 16))) &&
+              (!residual2 || (ldr2 % ve == 0 && aligned_to(residual2, 16))) &&
               (!gradpre || (ldg % ve == 0 && aligned_to(gradpre, 16))) &&
               (!pre_out || aligned_to(pre_out, 16));
   EpiQkv<T> eq{};
@@ -1338,15 +1352,16 @@ extern "C" int vy_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t 
 }
 
 extern "C" int vy_linear_dgrad(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const void* pre,
-                               int64_t ldpre, int act, const void* add_to, int64_t ldadd, void* dx,
-                               int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype, void* stream) {
+                               int64_t ldpre, int act, const void* add_to, int64_t ldadd, const void* add_to2,
+                               int64_t ldadd2, void* dx, int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype,
+                               void* stream) {
   // dX[M,K] = dY[M,N] . W[N,K] = dY . (W^T)^T with W^T stored [K,N]: an NT GEMM whose
   // "N" is K and whose contraction runs over N.
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VY_BF16)
-    return linear_impl<bf16>(dy, lddy, wt, ldwt, nullptr, add_to, ldadd, pre, ldpre, dx, lddx, nullptr, M, K, N, act, true, st, "vy_linear_dgrad");
+    return linear_impl<bf16>(dy, lddy, wt, ldwt, nullptr, add_to, ldadd, pre, ldpre, dx, lddx, nullptr, M, K, N, act, true, st, "vy_linear_dgrad", add_to2, ldadd2);
   if (dtype == VY_F32)
-    return linear_impl<float>(dy, lddy, wt, ldwt, nullptr, add_to, ldadd, pre, ldpre, dx, lddx, nullptr, M, K, N, act, true, st, "vy_linear_dgrad");
+    return linear_impl<float>(dy, lddy, wt, ldwt, nullptr, add_to, ldadd, pre, ldpre, dx, lddx, nullptr, M, K, N, act, true, st, "vy_linear_dgrad", add_to2, ldadd2);
   VY_FAIL(VY_ERR_ARG, "vy_linear_dgrad: bad dtype %d", dtype);
 }
 

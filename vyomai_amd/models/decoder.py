@@ -14,6 +14,7 @@ from ..layers.attention import _SelfAttentionBase
 from ..layers.ffn import FeedForward
 from ..layers.kv_cache import DynamicCacheOne, StaticCacheOne
 from ..layers.mask import AttnMask
+from ..autograd_train import defer_residual_grads as _defer
 from .common import LMHead, PositionMixin
 
 
@@ -77,6 +78,7 @@ class DecoderLayer(nn.Module):
 
     def forward(self, hidden_state, attention_mask, freqs=None, use_cache: Optional[bool] = False,
                 kv_cache=None, start_pos: Optional[int] = 0):
+        _defer(hidden_state)  # training: its residual-path gradients are added in the QKV dgrad epilogue
         out, kv_cache = self.attention(hidden_state=hidden_state, attention_mask=attention_mask, freqs=freqs,
                                        use_cache=use_cache, kv_cache=kv_cache, start_pos=start_pos)
         return self.feed_forward(out, hidden_state), kv_cache

@@ -10,6 +10,7 @@ import torch.nn as nn
 from ..layers.attention import EncoderAttention, EncoderAttentionGqa
 from ..layers.ffn import FeedForward
 from ..layers.mask import AttnMask
+from ..autograd_train import defer_residual_grads as _defer
 from .common import LMHead, PositionMixin
 
 
@@ -37,6 +38,7 @@ class EncoderLayer(nn.Module):
         self.layer_idx = layer_idx
 
     def forward(self, hidden_state, attention_mask, freqs=None) -> torch.Tensor:
+        _defer(hidden_state)  # training: its residual-path gradients are added in the QKV dgrad epilogue
         out = self.attention(hidden_state=hidden_state, attention_mask=attention_mask, freqs=freqs)
         return self.feed_forward(out, hidden_state)
 

@@ -20,6 +20,7 @@ from ..layers.attention import (DecoderAttention, DecoderAttentionGqa, EncoderDe
 from ..layers.ffn import FeedForward
 from ..layers.kv_cache import DynamicCache, StaticCache  # noqa: F401  (re-exported like the reference)
 from ..layers.mask import AttnMask
+from ..autograd_train import defer_residual_grads as _defer
 from .common import PositionMixin
 from .encoder import EncoderModel
 
@@ -49,6 +50,7 @@ class Seq2SeqDecoderLayer(nn.Module):
     def forward(self, hidden_state: torch.Tensor, attention_mask, encoder_hidden_state: Optional[torch.Tensor] = None,
                 encoder_attention_mask=None, freqs=None, use_cache: Optional[bool] = False,
                 start_pos: Optional[int] = 0) -> torch.Tensor:
+        _defer(hidden_state)  # training: its residual-path gradients are added in the QKV dgrad epilogue
         out = self.attention(hidden_state=hidden_state, attention_mask=attention_mask, freqs=freqs,
                              use_cache=use_cache, start_pos=start_pos)
         out = self.cross_attention(hidden_state=out, encoder_hidden_state=encoder_hidden_state,

@@ -182,9 +182,12 @@ def rope_tables(head_dim: int, max_pos: int, device) -> Tuple[Tensor, Tensor]:
 
 
 def linear_dgrad(dy: Tensor, wt: Tensor, pre: Optional[Tensor] = None, act: int = _lib.ACT_NONE,
-                 add_to: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
-    """dX = (dY @ W) * act'(pre) + add_to, with W^T given ([K, N] row-major).  (vy_linear_dgrad)"""
-    _need_gpu(dy, wt, pre, add_to)
+                 add_to: Optional[Tensor] = None, out: Optional[Tensor] = None,
+                 add_to2: Optional[Tensor] = None) -> Tensor:
+    """dX = (dY @ W) * act'(pre) + add_to + add_to2, with W^T given ([K, N] row-major).  (vy_linear_dgrad)"""
+    _need_gpu(dy, wt, pre, add_to, add_to2)
+    if add_to is None and add_to2 is not None:
+        add_to, add_to2 = add_to2, None
     d2 = _rows(dy)
     M, N = d2.shape
     K = wt.shape[0]
@@ -194,8 +197,10 @@ def linear_dgrad(dy: Tensor, wt: Tensor, pre: Optional[Tensor] = None, act: int 
     o2 = _rows(out)
     p2 = _rows(pre) if pre is not None else None
     a2 = _rows(add_to) if add_to is not None else None
+    b2 = _rows(add_to2) if add_to2 is not None else None
     call("vy_linear_dgrad", d2.data_ptr(), d2.stride(0), wt.data_ptr(), wt.stride(0), _ptr(p2),
          p2.stride(0) if p2 is not None else 0, act, _ptr(a2), a2.stride(0) if a2 is not None else 0,
+         _ptr(b2), b2.stride(0) if b2 is not None else 0,
          o2.data_ptr(), o2.stride(0), M, N, K, dtype_code(dy.dtype), _stream())
     return out
 
