@@ -240,7 +240,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
   };
 
   if constexpr (EPI == 0) {
-    auto flush_plain = [&](bf16* __restrict__ dst, bool final_pass) {
+    // The staged tile holds the PRE-activation (bf16).  The activation is applied HERE, to those bf16
+    // values -- what the reference's bf16 Linear -> GELU computes -- and, when the caller wants the
+    // pre-activation saved for backward (dual), it is stored from the same chunk: one pass over the
+    // tile, no second staging pass, no GELU chains among the accumulator registers.
+    auto flush_plain = [&](bf16* __restrict__ dst, bool final_pass, bool dual) {
       for (int c = tid; c < BM * CPR; c += NT) {
         const int row = c / CPR, cc = c - row * CPR;
         const int64_t m = m0 + row;
@@ -250,6 +254,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)sv[e];
+        if (dual) {
+          if (ep.vec_ok && n + 8 <= N) {
+            *reinterpret_cast<bf16x8*>(ep.pre + m * ep.ldy + n) = sv;
+          } else {
+            for (int e = 0; e < 8 && n + e < N; ++e) ep.pre[m * ep.ldy + n + e] = sv[e];
+          }
+        }
+        if constexpr (!GRAD && ACT != VY_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = vy_act_fwd_fast<ACT>(v[e]);
+        }
         if (ep.vec_ok && n + 8 <= N) {
           if (final_pass) {
             if constexpr (GRAD) {
@@ -289,9 +304,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
         }
       }
     };
-    const int passes = ep.pre ? 2 : 1;
-    for (int pass = 0; pass < passes; ++pass) {
-      const bool final_pass = pass == passes - 1;
+    const bool dual = !GRAD && ep.pre != nullptr;   // (the GRAD path never sets ep.pre)
+    {
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -302,19 +316,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
           for (int j = 0; j < TM; ++j) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v[e] = acc[i][j][4 * rg + e] + bq[e];
-              if constexpr (!GRAD) { if (final_pass) v[e] = vy_act_fwd_fast<ACT>(v[e]); }
-            }
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] + bq[e];
             stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
-            // keep the activation of one quad from being interleaved with the next ones: the
-            // unrolled erf/tanh chains otherwise cost >256 VGPRs and spill
-            if constexpr (ACT != VY_ACT_NONE && !GRAD) __builtin_amdgcn_sched_barrier(0);
           }
         }
       __syncthreads();
-      flush_plain(final_pass ? ep.y : ep.pre, final_pass);
-      if (!final_pass) __syncthreads();
+      flush_plain(ep.y, true, dual);
     }
   } else {
     // QKV: bias in registers; RoPE and the head-split scatter in phase 2, where a rotary pair
