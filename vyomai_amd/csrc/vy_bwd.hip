@@ -89,21 +89,41 @@ __global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kerne
     b_off[t] = (off ^ ((row & 3) << 6)) >> 1;
   }
   const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
+  // Per-piece source pointers are advanced by MS rows per stage (one 64-bit add each) instead of being
+  // rebuilt from row * ld every stage (the 64-bit multiplies and selects were ~120 instructions per
+  // stage and wave, next to 16 MFMAs).  A lane whose columns lie beyond N / K reads the zero page all
+  // along; only the LAST stage of a chunk can have rows beyond m_end and takes the checked path.
+  const bf16* a_ptr[PA]; const bf16* b_ptr[PB];
+  int64_t a_step[PA], b_step[PB];
+#pragma unroll
+  for (int t = 0; t < PA; ++t) {
+    const bool ok = n0 + a_off[t] < N;
+    a_ptr[t] = ok ? dY + (int64_t)(m_begin + a_row[t]) * lddy + n0 + a_off[t] : zero;
+    a_step[t] = ok ? (int64_t)MS * lddy : 0;
+  }
+#pragma unroll
+  for (int t = 0; t < PB; ++t) {
+    const bool ok = k0 + b_off[t] < K;
+    b_ptr[t] = ok ? X + (int64_t)(m_begin + b_row[t]) * ldx + k0 + b_off[t] : zero;
+    b_step[t] = ok ? (int64_t)MS * ldx : 0;
+  }
+  const bool ragged = ((m_end - m_begin) % MS) != 0;   // the last stage holds fewer than MS rows
   auto stage = [&](int s, int buf) {
-    const int mb = m_begin + s * MS;
+    const bool tail = ragged && s == nst - 1;
+    const int rows = m_end - (m_begin + s * MS);
 #pragma unroll
     for (int t = 0; t < PA; ++t) {
-      const int m = mb + a_row[t];
-      const bf16* a = (m < m_end && n0 + a_off[t] < N) ? dY + (int64_t)m * lddy + n0 + a_off[t] : zero;
+      const bf16* a = (tail && a_row[t] >= rows) ? zero : a_ptr[t];
       __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)a,
                                        (VY_LDS void*)(smem + buf * STAGE + (wave * PA + t) * 1024), 16, 0, 0);
+      a_ptr[t] += a_step[t];
     }
 #pragma unroll
     for (int t = 0; t < PB; ++t) {
-      const int m = mb + b_row[t];
-      const bf16* b = (m < m_end && k0 + b_off[t] < K) ? X + (int64_t)m * ldx + k0 + b_off[t] : zero;
+      const bf16* b = (tail && b_row[t] >= rows) ? zero : b_ptr[t];
       __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)b,
                                        (VY_LDS void*)(smem + buf * STAGE + ATILE + (wave * PB + t) * 1024), 16, 0, 0);
+      b_ptr[t] += b_step[t];
     }
   };
 
