@@ -202,3 +202,32 @@ def test_transpose_batched():
         ops.TransposeBatch(pairs).run()
         for src, dst in pairs:
             assert torch.equal(dst, src.t()), (src.shape, dt)
+
+
+def test_unfused_lm_head_backward_matches_fused_loss():
+    """Training through model(...).logits + torch cross-entropy (LMHeadFn: the gradient arrives
+    unpadded, vocabulary 1031 is odd) gives the gradients of the fused clm_loss path."""
+    import vyomai_amd as V
+    from vyomai_amd.training import FlatTrainer
+    grads = []
+    for fused in (True, False):
+        cfg = cases.test_cfg()
+        cfg.num_hidden_layers, cfg.vocab_size, cfg.hidden_dropout_prob = 2, 1031, 0.0
+        m = V.DecoderModel(cfg, "rope", None)
+        recipe.load_recipe_(m)
+        m = m.to(DEV).train()
+        ids = T(recipe.token_ids("train.ids", (4, 48), 3, cfg.vocab_size)).to(DEV)
+        tr = FlatTrainer(m, lr=1e-3)
+        tr.zero_grad()
+        if fused:
+            loss = m.clm_loss(ids, ids)
+        else:
+            logits = m(ids).logits
+            loss = torch.nn.functional.cross_entropy(logits[:, :-1].float().reshape(-1, cfg.vocab_size),
+                                                     ids[:, 1:].reshape(-1))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append((loss.item(), tr.arena.grad.clone()))
+    assert abs(grads[0][0] - grads[1][0]) < 2e-2
+    err = (grads[0][1] - grads[1][1]).abs().max() / grads[0][1].abs().max()
+    assert err < 3e-2, err

@@ -445,11 +445,17 @@ class LMHeadFn(torch.autograd.Function):
         wd, bd, ln_w, ln_b, wv, bias = ctx.params
         dt = hidden.dtype
         V, ld = wv.shape[0], ctx.ld
-        if dlogits.stride(-1) != 1 or dlogits.stride(-2) != ld:
+        # the contraction of the dgrad GEMM runs over the PADDED vocabulary width (multiple of 8, pad
+        # columns of both operands zero): re-home the gradient unless it already sits in such a buffer
+        if dlogits.stride(-1) != 1 or dlogits.stride(-2) != ld or dlogits.dtype != dt:
             buf = torch.zeros((*dlogits.shape[:-1], ld), dtype=dt, device=dlogits.device)
             buf[..., :V] = dlogits
-            dlogits = buf[..., :V]
-        dn = ops.linear_dgrad(dlogits, _wt(wv, dt))
+        else:
+            buf = torch.as_strided(dlogits, (*dlogits.shape[:-1], ld), dlogits.stride())
+            if ld != V:
+                buf[..., V:].zero_()
+        dlogits = buf[..., :V]
+        dn = ops.linear_dgrad(buf, _wt_padded(wv, dt, ld))
         dwv, dbias = _wgrad(dlogits, n, wv, bias)
         dg, dgam, dbet = _ln_bwd(dn, g, ln_w, ln_b, mean, rstd)
         dpre = _gelu_bwd(dg, pre)
