@@ -178,10 +178,11 @@ class DecoderModel(nn.Module, PositionMixin):
                 logits, _ = plan.step(hidden[:, 0, :].contiguous(), prev_pos)
                 next_token_logits = logits / temperature
             else:
-                outputs = self.forward(input_ids=tokens[:, prev_pos:cur_pos], attention_mask=attention_mask,
-                                       use_cache=use_cache, kv_cache=kv_cache, start_pos=prev_pos)
-                kv_cache = outputs.kv_cache
-                next_token_logits = outputs.logits[:, -1] / temperature
+                # only the last position's logits are used (reference :478-489 slices them out of the full
+                # (B, L, V) tensor): the vocabulary projection runs on that one row per sequence
+                hidden, kv_cache = self.forward_hidden(tokens[:, prev_pos:cur_pos], attention_mask, use_cache,
+                                                       kv_cache, prev_pos)
+                next_token_logits = self.lm_head(hidden[:, -1:, :].contiguous())[:, -1] / temperature
             if do_sample:
                 # the reference samples from the raw logits (:491-492); kept
                 next_token = torch.multinomial(next_token_logits.float(), num_samples=1)
