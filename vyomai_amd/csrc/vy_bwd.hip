@@ -359,7 +359,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdParams p) {
   const int64_t stat = ((int64_t)b * p.h + head) * p.L + qrow;
   const float c = p.scale * LOG2E;
   float neg_lse = -p.lse[stat] * LOG2E;  // p = exp2(c*s + neg_lse)
-  float neg_delta = p.delta[stat];       // the delta kernel stores -delta
+  // -delta = -sum_d dO*O of this lane's query row: the dO fragments are already here, O costs four
+  // more 16-byte loads, the two lane halves (d 8fh..8fh+7 of every 16) are added by one exchange.
+  // Written to the workspace for the dK/dV kernel, which is launched after this one.
+  float neg_delta;
+  {
+    const bf16* Op = p.o + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + head * DH;
+    float acc_ = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(Op + ks * 16 + fh * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc_ += (float)of[e] * (float)gf[ks][e];
+    }
+    acc_ += __shfl_xor(acc_, 32, 64);
+    neg_delta = -acc_;
+    if (fh == 0 && qi < p.L) p.delta[stat] = neg_delta;
+  }
   const bool causal = p.mask_kind & VY_MASK_CAUSAL;
   const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
   const uint8_t* kp = haskp ? p.keypad + (int64_t)b * p.kp_sb : nullptr;
@@ -830,8 +846,8 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   if ((cos_tab == nullptr) != (sin_tab == nullptr)) VY_FAIL(VY_ERR_ARG, "%s: cos/sin must both be given", who);
   p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.rope_pos0 = (int)rope_pos0;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)vy_cdiv(B * L, 4)), dim3(256), 0, st, p);
-  VY_CHECK_LAUNCH("vy_attn_bwd(delta)");
+  // (delta = rowsum(dO * O) is computed by the dQ kernel for its own rows and left in delta_ws for the
+  // dK/dV kernel; attn_delta_kernel remains for reference)
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(h * B), (unsigned)((L + 127) / 128), 1), dim3(256), 0, st, p);
   VY_CHECK_LAUNCH("vy_attn_bwd(dq)");
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(hk * B), (unsigned)((S + 127) / 128), 1), dim3(256), 0, st, p);
