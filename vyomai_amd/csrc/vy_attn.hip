@@ -347,21 +347,35 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     }
   }
   const float inv = 1.0f / l_tot;
-  if (p.diag == 1 && o[0][0] != 12345.678f) return;
-  if (qi < p.L) {
-    bf16* O = (bf16*)p.out + (int64_t)b * p.o_sb + (int64_t)qi * p.o_sl + head * DH;
+  // The wave's 32 x DH output tile goes through LDS so that HBM sees whole 16-byte-per-lane row
+  // segments (8 or 16 lanes = one row's DH*2 bytes) instead of 8-byte pieces of 32 different rows per
+  // store instruction.  Every wave has left the tile loop once the barrier below is passed; each wave
+  // then uses a private slice of the (now idle) K ring.
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  constexpr int OROW = RB + 16;                       // padded row pitch of the staged tile
+  char* ot = smem + wave * (32 * OROW);
 #pragma unroll
-    for (int n = 0; n < ND; ++n)
+  for (int n = 0; n < ND; ++n)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        bf16x4 w;
+    for (int rg = 0; rg < 4; ++rg) {
+      bf16x4 w;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = (bf16)(o[n][4 * rg + e] * inv);
-        *reinterpret_cast<bf16x4*>(O + 32 * n + 8 * rg + 4 * fh) = w;
-      }
-    if (p.lse && fh == 0)
-      p.lse[((int64_t)b * p.h + head) * p.L + qi] = (m_run + log2f(l_tot)) * LN2;
+      for (int e = 0; e < 4; ++e) w[e] = (bf16)(o[n][4 * rg + e] * inv);
+      *reinterpret_cast<bf16x4*>(ot + fr * OROW + (32 * n + 8 * rg + 4 * fh) * 2) = w;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: no barrier needed
+  constexpr int LPR = RB / 16;                         // lanes per output row
+#pragma unroll
+  for (int it = 0; it < 32 * LPR / 64; ++it) {
+    const int r = (it * 64 + lane) / LPR, ch = (it * 64 + lane) % LPR;
+    const int qrow_ = q0 + wave * 32 + r;
+    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(ot + r * OROW + ch * 16);
+    if (qrow_ < p.L)
+      *reinterpret_cast<bf16x8*>((bf16*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow_ * p.o_sl + head * DH + ch * 8) = vv;
   }
+  if (qi < p.L && p.lse && fh == 0)
+    p.lse[((int64_t)b * p.h + head) * p.L + qi] = (m_run + log2f(l_tot)) * LN2;
 }
 
 // ------------------------------------------------------------------------------------------
