@@ -624,17 +624,24 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
   const int xrow_off = (wm * 32 * TM + fr) * ROWB;
   const int wrow_off = (wn * 32 * TN + fr) * ROWB;
 
-  bf16x8 wf[2][TN], xf[2][TM];
-  auto read_frags = [&](int kt, int ks, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
-    const char* xb = smem + (kt % 3) * XT;
-    const char* wb = smem + WOFF + (kt & 1) * WT;
+  // hidden fragment reads with counted lgkmcnt (as in gemm_nt_bf16_kernel)
+  unsigned xa[4], wa[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
     const int coff = (((ks * 2 + fh) ^ fsw) << 4);
+    xa[ks] = vy_lds_addr(smem) + xrow_off + coff;
+    wa[ks] = vy_lds_addr(smem) + WOFF + wrow_off + coff;
+  }
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; w_[i] = vy_lds_read128_off<i * 32 * ROWB>(wbase); });
+    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; x_[j] = vy_lds_read128_off<j * 32 * ROWB>(xbase); });
+  };
+  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
-      w_[i] = *reinterpret_cast<const bf16x8*>(wb + wrow_off + i * 32 * ROWB + coff);
+    for (int i = 0; i < TN; ++i) vy_tie(w_[i]);
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
-      x_[j] = *reinterpret_cast<const bf16x8*>(xb + xrow_off + j * 32 * ROWB + coff);
+    for (int j = 0; j < TM; ++j) vy_tie(x_[j]);
   };
 
   // the wave's LDS-DMA queue, oldest first, at the wait that ends slice kt: X(kt+1), W(kt+1), X(kt+2)
@@ -645,13 +652,21 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  read_frags(0, 0, wf[0], xf[0]);
+  read_frags(wa[0], xa[0], wf[0], xf[0]);
+  int xbuf = 0;   // kt % 3
   for (int kt = 0; kt < KT; ++kt) {
     if (kt + 1 < KT) stage_w(kt + 1);
     if (kt + 2 < KT) stage_x(kt + 2);
+    const unsigned xo = xbuf * XT, wo = (kt & 1) * WT;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) read_frags(kt, ks + 1, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+      if (ks < 3) {
+        read_frags(wa[ks + 1] + wo, xa[ks + 1] + xo, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      tie_frags(wf[ks & 1], xf[ks & 1]);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
@@ -664,7 +679,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 1 < KT) read_frags(kt + 1, 0, wf[0], xf[0]);
+    xbuf = xbuf == 2 ? 0 : xbuf + 1;
+    if (kt + 1 < KT) read_frags(wa[0] + (WT - wo), xa[0] + xbuf * XT, wf[0], xf[0]);
   }
   gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
 }
@@ -1185,7 +1201,11 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     // multiples of the 256 CUs; 256 x 256 (fewer L2 bytes per FLOP) where N is wide enough for
     // whole rounds anyway (FFN1, vocabulary).  VY_GEMM_VARIANT selects the experimental ring
     // kernels (0-2) or forces a tile (8/9) for A/B runs in one process.
-    static const int var = [] { const char* e = getenv("VY_GEMM_VARIANT"); return e ? atoi(e) : -1; }();
+    // Default (var < 0): N >= 3072 -> two-stage 256 x 256; otherwise 256 x 192 with the X operand in a
+    // three-deep ring (gemm_nt_bf16_x3_kernel): equal or slightly slower on warm micro-benchmarks, +1 %
+    // inside the training step where the activations come from HBM/MALL.  16 = the two-stage 256 x 192.
+    static const int var0 = [] { const char* e = getenv("VY_GEMM_VARIANT"); return e ? atoi(e) : -1; }();
+    const int var = var0 < 0 ? 14 : (var0 == 16 ? -1 : var0);
     const bool wide = (N >= 3072);
     if (var == 8 || (var < 0 && wide)) {
       const int tn2 = (int)vy_cdiv(N, 256);
@@ -1202,9 +1222,17 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     } else if (var == 11) {  // 4 waves, 128 x 96 per wave
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
-    } else if (var == 13) {  // X in a 3-deep ring (counted waits across the barrier), W in two buffers
+    } else if (var == 13 || (var == 14 && !wide) || (var == 15 && !wide)) {  // X in a 3-deep ring, W in two buffers
       hipLaunchKernelGGL((gemm_nt_bf16_x3_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    } else if (var == 15) {  // ... and the 256-wide tile for N >= 3072 in the same form (160 KiB of LDS)
+      const int tn2 = (int)vy_cdiv(N, 256);
+      hipLaunchKernelGGL((gemm_nt_bf16_x3_kernel<256, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq);
+    } else if (var == 14) {  // wide shapes keep the two-stage 256 x 256 kernel
+      const int tn2 = (int)vy_cdiv(N, 256);
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
     } else if (var == 9 || var < 0) {
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
