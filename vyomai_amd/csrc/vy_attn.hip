@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   constexpr int NP = TILE / 1024 / 4;   // 1-KiB LDS-DMA pieces per wave per tile
   constexpr int KS = DH / 16;           // k-steps of the QK^T contraction
   constexpr int ND = DH / 32;           // 32-wide d blocks of O^T
-  constexpr int NS = 3;                 // K/V tiles in the LDS ring: NS - 1 tiles of loads in flight
+  constexpr int NS = 3;                 // K/V tiles in the LDS ring: NS - 1 tiles of loads in flight (4: no gain)
   constexpr int KPW = 256;              // key-padding visibility words (64 keys each): S <= 16384
   // ONE shared object (a second one makes hipcc wait vmcnt(0) before every ds_read while LDS-DMA
   // is in flight): K ring, V ring, then 4 flag words for the block-wide OR below
@@ -275,13 +275,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
   // 2*NP LDS-DMA instructions are the oldest outstanding ones of the wave) and one raw s_barrier per
   // tile; nothing in the loop drains the memory pipe, so the L2/HBM latency of a tile is covered
   // by the softmax + MFMA work of the previous tiles instead of being paid once per tile.
-  auto wait_tile = [&](int younger) {
-    if (younger >= 1) {
-      if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  auto wait_tile = [&](int younger) {   // `younger` tiles (2*NP LDS-DMA instructions each) may stay in flight
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NP) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   // The Q fragments came through ordinary loads: make the compiler retire them HERE (an asm that
   // reads them), before any LDS-DMA is in flight -- otherwise its wait for them sits at the first
