@@ -46,6 +46,9 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
 // NS stages of LDS: the loads of the next NS-1 stages are in flight while a stage is multiplied; a
 // stage is waited for with a COUNTED vmcnt (its PA+PB LDS-DMA instructions are the wave's oldest)
 // and one raw s_barrier.
+// NS == 0 selects the asymmetric ring: the dY tile three deep, the X tile two deep (3*ATILE + 2*BTILE =
+// 80 KiB at 128 x 128 x 64: still two workgroups per CU) -- the dY loads of stage s+2 stay in flight
+// across the barrier that ends stage s, as X does in gemm_nt_bf16_x3_kernel.
 template <int BN, int BKW, int MS, int NS>
 __global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kernel(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
@@ -59,7 +62,8 @@ __global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kerne
   constexpr int PA = ATILE / 1024 / NW, PB = BTILE / 1024 / NW;  // LDS-DMA pieces per wave
   constexpr int KS = MS / 16;
   static_assert(PA * 1024 * NW == ATILE && PB * 1024 * NW == BTILE && (KS == 2 || KS == 4), "tile / wave layout mismatch");
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  constexpr bool A3 = NS == 0;
+  __shared__ __attribute__((aligned(16))) char smem[A3 ? 3 * ATILE + 2 * BTILE : NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
@@ -108,23 +112,29 @@ __global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kerne
     b_step[t] = ok ? (int64_t)MS * ldx : 0;
   }
   const bool ragged = ((m_end - m_begin) % MS) != 0;   // the last stage holds fewer than MS rows
-  auto stage = [&](int s, int buf) {
+  auto stage_a = [&](int s, char* dst) {
     const bool tail = ragged && s == nst - 1;
     const int rows = m_end - (m_begin + s * MS);
 #pragma unroll
     for (int t = 0; t < PA; ++t) {
       const bf16* a = (tail && a_row[t] >= rows) ? zero : a_ptr[t];
-      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)a,
-                                       (VY_LDS void*)(smem + buf * STAGE + (wave * PA + t) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)a, (VY_LDS void*)(dst + (wave * PA + t) * 1024), 16, 0, 0);
       a_ptr[t] += a_step[t];
     }
+  };
+  auto stage_b = [&](int s, char* dst) {
+    const bool tail = ragged && s == nst - 1;
+    const int rows = m_end - (m_begin + s * MS);
 #pragma unroll
     for (int t = 0; t < PB; ++t) {
       const bf16* b = (tail && b_row[t] >= rows) ? zero : b_ptr[t];
-      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)b,
-                                       (VY_LDS void*)(smem + buf * STAGE + ATILE + (wave * PB + t) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)b, (VY_LDS void*)(dst + (wave * PB + t) * 1024), 16, 0, 0);
       b_ptr[t] += b_step[t];
     }
+  };
+  auto stage = [&](int s, int buf) {
+    stage_a(s, smem + buf * STAGE);
+    stage_b(s, smem + buf * STAGE + ATILE);
   };
 
   f32x16 acc[2][TJ];
@@ -154,26 +164,48 @@ __global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kerne
 #pragma unroll
   for (int j = 0; j < TJ; ++j) b_lds[j] = vy_lds_addr(smem) + tr_row * BROW + ((b_rd + 64 * j) ^ tr_sw);
 
+  if constexpr (A3) {
+    stage_a(0, smem);
+    stage_b(0, smem + 3 * ATILE);
+    if (nst > 1) stage_a(1, smem + ATILE);
+  } else {
 #pragma unroll
-  for (int s_ = 0; s_ < NS - 1; ++s_)
-    if (s_ < nst) stage(s_, s_);
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+      if (s_ < nst) stage(s_, s_);
+  }
+  int abuf = 0;   // s % 3 (A3)
   for (int s = 0; s < nst; ++s) {
-    const int cur = s % NS;
-    const int younger = min(NS - 2, nst - 1 - s);  // stages issued after stage s
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PA + PB)) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (s + NS - 1 < nst) stage(s + NS - 1, (s + NS - 1) % NS);  // the buffer stage s-1 was read from
+    unsigned a_base[2], b_base[TJ];
+    if constexpr (A3) {
+      // the wave's queue, oldest first: A(s), B(s), A(s+1) -- the youngest PA instructions may stay
+      if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + 1 < nst) stage_b(s + 1, smem + 3 * ATILE + ((s + 1) & 1) * BTILE);
+      if (s + 2 < nst) stage_a(s + 2, smem + (abuf == 0 ? 2 : abuf - 1) * ATILE);   // (s + 2) % 3
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a_base[i] = a_lds[i] + abuf * ATILE;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b_base[j] = b_lds[j] + 2 * ATILE + (s & 1) * BTILE;
+      abuf = abuf == 2 ? 0 : abuf + 1;
+    } else {
+      const int cur = s % (NS > 0 ? NS : 1);
+      const int younger = min(NS - 2, nst - 1 - s);  // stages issued after stage s
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PA + PB)) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + NS - 1 < nst) stage(s + NS - 1, (s + NS - 1) % (NS > 0 ? NS : 1));  // the buffer stage s-1 was read from
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a_base[i] = a_lds[i] + cur * STAGE;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) b_base[j] = b_lds[j] + cur * STAGE;
+    }
     // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (asm reads + counted
     // lgkmcnt: see vy_common.h -- the builtin form would drain the LDS-DMA prefetch first).  One
     // base address per fragment column; the k-step and the +8 row go into the offset field.
-    unsigned a_base[2], b_base[TJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a_base[i] = a_lds[i] + cur * STAGE;
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) b_base[j] = b_lds[j] + cur * STAGE;
     bf16x8 af[2][2], bfr[2][TJ];
     auto frags = [&](auto ks_c, bf16x8* a_, bf16x8* b_) {
       constexpr int ks = decltype(ks_c)::value;
@@ -805,6 +837,7 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   else if (var == 2) WG_GO(128, 256, 32, 2);
   else if (var == 4) WG_GO(128, 256, 32, 3);
   else if (var == 5) WG_GO(128, 128, 32, 2);   // 32 KiB of LDS: three workgroups per CU
+  else if (var == 6) WG_GO(128, 128, 64, 0);   // dY three deep, X two deep: 80 KiB, two workgroups per CU
   else { if (ns == 3) WG_GO(128, 128, 64, 3); else WG_GO(128, 128, 64, 2); }
 #undef WG_GO
   VY_CHECK_LAUNCH(who);
