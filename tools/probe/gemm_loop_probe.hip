@@ -1,0 +1,230 @@
+// The bf16 GEMM k-loop (256 x 192 x 64 stages, 8 waves, LDS-DMA, hidden ds_read_b128, MFMA 32x32x16)
+// WITHOUT an epilogue, with its three ingredients switchable at compile time and several issue
+// schedules, timed in shader clocks per stage (s_memtime) -- which ingredient fails to overlap?
+//   MODE bits: 1 = LDS-DMA loads, 2 = fragment reads, 4 = MFMAs
+//   SCHED: 0 = a wave issues its 7 loads at the start of the stage (the library's two-stage kernel)
+//          1 = loads spread over the k-steps (2,2,2,1) -- lands late with two stages
+//          2 = THREE stages of 256 x 128 (144 KiB): loads of stage kt+2 spread over stage kt
+//          3 = as 0 but the two waves of a SIMD are skewed by half a stage (waves 4-7 issue their
+//              loads after k-step 1)
+//   hipcc --offload-arch=gfx950 -O3 -o gemm_loop_probe gemm_loop_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <vector>
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define LDS __attribute__((address_space(3)))
+#define GLB __attribute__((address_space(1)))
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(unsigned a) {
+  bf16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF) : "memory");
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)(LDS const char*)p; }
+template <typename T> __device__ __forceinline__ void tie(T& v) { asm volatile("" : "+v"(v)); }
+
+template <int MODE, int SCHED, int BN>
+__global__ __launch_bounds__(512) void kloop(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+                                             int64_t ldw, int K, int tiles_n, unsigned long long* clk, float* sink) {
+  constexpr int BM = 256, BK = 64, ROWB = 128, NW = 8, WGN = 2;
+  constexpr int TM = 2, TN = BN / 64;
+  constexpr int PX = BM / 8, PW = BN / 8, GX = PX / NW, GW = PW / NW;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int NS = SCHED == 2 ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+  constexpr bool LOADS = MODE & 1, READS = MODE & 2, MFMA = MODE & 4;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  // XCD-aware remap as in the library
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int KT = K / BK;
+
+  const int lrow = lane >> 3, slot = lane & 7;
+  const bf16* xsrc[GX];
+  const bf16* wsrc[GW];
+#pragma unroll
+  for (int t = 0; t < GX; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    xsrc[t] = X + (int64_t)(m0 + R) * ldx + (slot ^ ((R >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    wsrc[t] = W + (int64_t)(n0 + R) * ldw + (slot ^ ((R >> 1) & 7)) * 8;
+  }
+  auto load_piece = [&](int kt, int pc) {   // pieces 0..GW-1 = W, GW.. = X  (W first: it must land first)
+    char* xb = smem + (kt % NS) * STAGE;
+    char* wb = xb + BM * ROWB;
+    if (pc < GW)
+      __builtin_amdgcn_global_load_lds((const GLB void*)(wsrc[pc] + kt * BK), (LDS void*)(wb + (wave + NW * pc) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const GLB void*)(xsrc[pc - GW] + kt * BK), (LDS void*)(xb + (wave + NW * (pc - GW)) * 1024), 16, 0, 0);
+  };
+  auto load_stage = [&](int kt) {
+#pragma unroll
+    for (int pc = 0; pc < GX + GW; ++pc) load_piece(kt, pc);
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  unsigned xa[4], wa[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
+    xa[ks] = lds_addr(smem) + (wm * 32 * TM + fr) * ROWB + coff;
+    wa[ks] = lds_addr(smem) + BM * ROWB + (wn * 32 * TN + fr) * ROWB + coff;
+  }
+  bf16x8 wf[2][TN], xf[2][TM];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wf[b][i][e] = (bf16)(float)((lane + e + i) % 7 - 3);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xf[b][j][e] = (bf16)(float)((lane * 3 + e + j) % 5 - 2);
+  }
+  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    if (!READS) return;
+    w_[0] = lds_read128<0>(wbase);
+    w_[1] = lds_read128<32 * ROWB>(wbase);
+    if constexpr (TN > 2) w_[2] = lds_read128<64 * ROWB>(wbase);
+    x_[0] = lds_read128<0>(xbase);
+    x_[1] = lds_read128<32 * ROWB>(xbase);
+  };
+  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) tie(w_[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) tie(x_[j]);
+  };
+  auto mma = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    if (!MFMA) return;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_[i], x_[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // prologue
+  if (LOADS) {
+    load_stage(0);
+    if (SCHED == 2 && KT > 1) load_stage(1);
+  }
+  if (SCHED == 2 && KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX + GW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  read_frags(wa[0], xa[0], wf[0], xf[0]);
+  int buf = 0;  // kt % NS
+  for (int kt = 0; kt < KT; ++kt) {
+    const int ahead = NS - 1;                       // stage issued during stage kt
+    const bool more = kt + ahead < KT;
+    const bool late = SCHED == 3 && wave >= 4;
+    if (LOADS && more && SCHED == 0) load_stage(kt + ahead);
+    if (LOADS && more && SCHED == 3 && !late) load_stage(kt + ahead);
+    const unsigned boff = buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (LOADS && more && (SCHED == 1 || SCHED == 2)) {   // spread: 2,2,2,1 (or fewer at BN = 128)
+        constexpr int NP = GX + GW;
+        const int lo = ks * NP / 4, hi = (ks + 1) * NP / 4;
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc)
+          if (pc >= lo && pc < hi) load_piece(kt + ahead, pc);
+      }
+      if (LOADS && more && late && ks == 2) load_stage(kt + ahead);
+      if (ks < 3) {
+        read_frags(wa[ks + 1] + boff, xa[ks + 1] + boff, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+        if (READS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      tie_frags(wf[ks & 1], xf[ks & 1]);
+      mma(wf[ks & 1], xf[ks & 1]);
+    }
+    if (SCHED == 2 && kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX + GW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    buf = buf + 1 == NS ? 0 : buf + 1;
+    if (kt + 1 < KT) read_frags(wa[0] + buf * STAGE, xa[0] + buf * STAGE, wf[0], xf[0]);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) s += acc[i][0][0] + acc[i][1][3];
+  if (s == 12345.678f) sink[0] = s;
+  if (tid == 0) clk[blockIdx.x] = t1 - t0;
+}
+
+static const bf16 *dX, *dW;
+static unsigned long long* dclk;
+static float* dsink;
+constexpr int M = 16384, K = 3072, N = 768;
+
+template <int MODE, int SCHED, int BN>
+void run(const char* what) {
+  const int tiles_n = N / BN, nwg = (M / 256) * tiles_n;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) kloop<MODE, SCHED, BN><<<nwg, 512>>>(dX, K, dW, K, K, tiles_n, dclk, dsink);
+  (void)hipEventRecord(e0);
+  const int reps = 10;
+  for (int w = 0; w < reps; ++w) kloop<MODE, SCHED, BN><<<nwg, 512>>>(dX, K, dW, K, K, tiles_n, dclk, dsink);
+  (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(nwg);
+  (void)hipMemcpy(h.data(), dclk, nwg * 8, hipMemcpyDeviceToHost);
+  double cyc = 0; for (int i = 0; i < nwg; ++i) cyc += h[i];
+  cyc /= nwg;
+  const double per_stage = cyc / (K / 64);
+  const double mf = 256.0 * BN * 64 * 2 / 4;   // flops per stage per SIMD -> MFMA cycles = flops / 1024
+  printf("%-58s BN %3d: %7.0f cycles/stage (MFMA alone %4.0f)  %7.1f us/launch  %6.1f TFLOP/s\n", what, BN, per_stage,
+         mf / 1024.0, ms * 1e3 / reps, (MODE & 4) ? 2.0 * M * N * K / (ms * 1e-3 / reps) * 1e-12 : 0.0);
+}
+
+int main() {
+  std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
+  unsigned s = 12345;
+  for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((s >> 9) & 0x3ff) | ((s >> 3) & 0x8000)); }
+  for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3800 + ((s >> 9) & 0x3ff) | ((s >> 3) & 0x8000)); }
+  (void)hipMalloc((void**)&dX, hx.size() * 2); (void)hipMalloc((void**)&dW, hw.size() * 2);
+  (void)hipMalloc(&dclk, 8192 * 8); (void)hipMalloc(&dsink, 64);
+  (void)hipMemcpy((void*)dX, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy((void*)dW, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+  run<4, 0, 192>("MFMA only");
+  run<2, 0, 192>("fragment reads only");
+  run<1, 0, 192>("LDS-DMA loads only (issue, wait, barrier)");
+  run<6, 0, 192>("MFMA + reads");
+  run<5, 0, 192>("MFMA + loads");
+  run<3, 0, 192>("loads + reads");
+  run<7, 0, 192>("all: loads at stage start (library two-stage kernel)");
+  run<7, 1, 192>("all: loads spread over the k-steps, two stages");
+  run<5, 1, 192>("MFMA + loads, spread");
+  run<7, 3, 192>("all: waves 4-7 issue their loads after k-step 1");
+  run<7, 0, 128>("all: 256x128 tile, two stages");
+  run<7, 2, 128>("all: 256x128 tile, three stages, spread");
+  run<5, 2, 128>("MFMA + loads: 256x128, three stages, spread");
+  return 0;
+}

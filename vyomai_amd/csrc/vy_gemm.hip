@@ -185,6 +185,21 @@ __device__ __forceinline__ void epi_qkv_quad(const EpiQkv<T>& e, float (&v)[4], 
   Quad<T>::store(qkv_dest(e, b, l, n), v);
 }
 
+// measurement aid (VY_GEMM_ROT bit 16): workgroup 0 accumulates its shader-clock cycles (s_memtime)
+// and 100 MHz ticks (s_memrealtime) here; vy_debug_gemm_clock() reads and clears them
+// (tools/gemm_clock.py): cycles / ticks * 100 = the shader clock in MHz the GEMMs really ran at.
+__device__ unsigned long long vy_gemm_clk[3];
+#define VY_CLK_BEGIN(on)                                                         \
+  const bool clk_on_ = (on) && blockIdx.x == 0 && threadIdx.x == 0;              \
+  unsigned long long clk_c0_ = 0, clk_w0_ = 0;                                   \
+  if (clk_on_) { clk_c0_ = __builtin_readcyclecounter(); clk_w0_ = wall_clock64(); }
+#define VY_CLK_END()                                                             \
+  if (clk_on_) {                                                                 \
+    atomicAdd(&vy_gemm_clk[0], __builtin_readcyclecounter() - clk_c0_);          \
+    atomicAdd(&vy_gemm_clk[1], wall_clock64() - clk_w0_);                        \
+    atomicAdd(&vy_gemm_clk[2], 1ull);                                            \
+  }
+
 // XCD-aware bijective block remap: blocks b, b+8, ... share an XCD (round-robin dispatch), give
 // each XCD a contiguous run of tile ids.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -391,6 +406,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
   constexpr int NW = WGM * WGN, NT = 64 * NW;
   constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
   static_assert(TM * 32 * WGM == BM && TN * 32 * WGN == BN, "tile / wave layout mismatch");
+  VY_CLK_BEGIN(rot_on & 16)
   constexpr int PX = BM / 8, PW = BN / 8;               // 1-KiB LDS-DMA pieces (8 rows) per stage
   constexpr int GX = (PX + NW - 1) / NW, GW = (PW + NW - 1) / NW;
   constexpr int STAGE = (BM + BN) * ROWB;
@@ -433,7 +449,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
   // run in lockstep and request the same not-yet-resident lines at once.  tools/probe/ldsdma_probe
   // shows the L2 merges such requests well (72 GB/s per CU for a 4-way shared stream against 28
   // unshared), and the rotation measured 1-5 % slower -- kept off.
-  const int rot = rot_on ? (tile_n * 2 + tile_m) % KT : 0;
+  const int rot = (rot_on & 1) ? (tile_n * 2 + tile_m) % KT : 0;
   auto stage = [&](int kt, int buf) {
     char* xb = smem + buf * STAGE;
     char* wb = xb + BM * ROWB;
@@ -534,6 +550,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
   }
   // the epilogue reuses the stage buffers: every LDS read above has been retired (last k-step: lgkmcnt(0))
   gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
+  VY_CLK_END()
 }
 
 // ------------------------------------------------------------------------------------------
@@ -549,9 +566,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
 template <int BN, int EPI, int ACT, bool GRAD>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
-    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq, int knob) {
   constexpr int BM = 256, WGM = 4, WGN = 2, NW = 8;
   constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
+  VY_CLK_BEGIN(knob & 16)
   constexpr int PX = BM / 8, PW = BN / 8;   // 1-KiB LDS-DMA pieces (8 rows x 128 B) per k-slice
   constexpr int GX = PX / NW, GW = PW / NW;
   static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
@@ -683,6 +701,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
     if (kt + 1 < KT) read_frags(wa[0] + (WT - wo), xa[0] + xbuf * XT, wf[0], xf[0]);
   }
   gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
+  VY_CLK_END()
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1224,11 +1243,11 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     } else if (var == 13 || (var == 14 && !wide) || (var == 15 && !wide)) {  // X in a 3-deep ring, W in two buffers
       hipLaunchKernelGGL((gemm_nt_bf16_x3_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     } else if (var == 15) {  // ... and the 256-wide tile for N >= 3072 in the same form (160 KiB of LDS)
       const int tn2 = (int)vy_cdiv(N, 256);
       hipLaunchKernelGGL((gemm_nt_bf16_x3_kernel<256, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq);
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
     } else if (var == 14) {  // wide shapes keep the two-stage 256 x 256 kernel
       const int tn2 = (int)vy_cdiv(N, 256);
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
@@ -1418,6 +1437,13 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
 // y = LN(x W^T + bias + residual) for M <= 32 rows (decode), bf16: split-K GEMM + fused finish.
 // `part` is an fp32 scratch of vy_splitk_ws_floats(N) elements.  Internal to the decode driver.
 int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N; }
+
+// measurement aid, not part of include/vyom_hip.h: {shader cycles, 10 ns ticks, launches} since the last call
+extern "C" int vy_debug_gemm_clock(unsigned long long* out3) {
+  unsigned long long z[3] = {0, 0, 0};
+  if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(vy_gemm_clk), sizeof(z)) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(vy_gemm_clk), z, sizeof(z)) != hipSuccess;
+}
 int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                             const void* residual, int64_t ldr, const void* gamma, const void* beta, float eps,
                             void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream) {
