@@ -28,8 +28,8 @@ __device__ __forceinline__ bf16x8 lds_read128(unsigned a) {
 __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)(LDS const char*)p; }
 template <typename T> __device__ __forceinline__ void tie(T& v) { asm volatile("" : "+v"(v)); }
 
-template <int MODE, int SCHED, int BN>
-__global__ __launch_bounds__(512) void kloop(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+template <int MODE, int SCHED, int BN, int LAYOUT = 0, int PF = 0>
+__global__ __launch_bounds__(PF ? 576 : 512) void kloop(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
                                              int64_t ldw, int K, int tiles_n, unsigned long long* clk, float* sink) {
   constexpr int BM = 256, BK = 64, ROWB = 128, NW = 8, WGN = 2;
   constexpr int TM = 2, TN = BN / 64;
@@ -50,6 +50,25 @@ __global__ __launch_bounds__(512) void kloop(const bf16* __restrict__ X, int64_t
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int KT = K / BK;
 
+  if (PF && wave == NW) {
+    // L2 warmer: one extra wave touches the lines of stage kt+PF (one dword per 128-byte line), its share
+    // of what the workgroups of this XCD that share the X tile (4 column tiles) / the W tile (8 row
+    // tiles) need; it never waits for data, it only keeps pace through the stage barrier
+    const bf16* px = X + (int64_t)(m0 + tile_n * 64 + lane) * ldx;                      // 64 of the 256 rows
+    const bf16* pw = W + (int64_t)(n0 + (tile_m & 7) * (BN / 8) + (lane % (BN / 8))) * ldw;  // BN/8 of the BN rows
+    float d0, d1;
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt + PF < KT) {
+        asm volatile("global_load_dword %0, %1, off" : "=v"(d0) : "v"(px + (kt + PF) * BK) : "memory");
+        if (lane < BN / 8) asm volatile("global_load_dword %0, %1, off" : "=v"(d1) : "v"(pw + (kt + PF) * BK) : "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (d0 == 12345.678f && d1 == 1.f) sink[1] = d0;
+    return;
+  }
   const int lrow = lane >> 3, slot = lane & 7;
   const bf16* xsrc[GX];
   const bf16* wsrc[GW];
@@ -57,19 +76,22 @@ __global__ __launch_bounds__(512) void kloop(const bf16* __restrict__ X, int64_t
   for (int t = 0; t < GX; ++t) {
     const int R = (wave + NW * t) * 8 + lrow;
     xsrc[t] = X + (int64_t)(m0 + R) * ldx + (slot ^ ((R >> 1) & 7)) * 8;
+    // LAYOUT 2: X stored tile-major, [tile_m][kt][256 rows][64] -- a stage of a tile is one 32-KiB block
+    if (LAYOUT == 2) xsrc[t] = X + (int64_t)tile_m * BM * ldx + R * 64 + (slot ^ ((R >> 1) & 7)) * 8;
   }
 #pragma unroll
   for (int t = 0; t < GW; ++t) {
     const int R = (wave + NW * t) * 8 + lrow;
     wsrc[t] = W + (int64_t)(n0 + R) * ldw + (slot ^ ((R >> 1) & 7)) * 8;
+    if (LAYOUT >= 1) wsrc[t] = W + (int64_t)tile_n * BN * ldw + R * 64 + (slot ^ ((R >> 1) & 7)) * 8;
   }
   auto load_piece = [&](int kt, int pc) {   // pieces 0..GW-1 = W, GW.. = X  (W first: it must land first)
     char* xb = smem + (kt % NS) * STAGE;
     char* wb = xb + BM * ROWB;
     if (pc < GW)
-      __builtin_amdgcn_global_load_lds((const GLB void*)(wsrc[pc] + kt * BK), (LDS void*)(wb + (wave + NW * pc) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB void*)(wsrc[pc] + kt * (LAYOUT >= 1 ? BN * 64 : BK)), (LDS void*)(wb + (wave + NW * pc) * 1024), 16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((const GLB void*)(xsrc[pc - GW] + kt * BK), (LDS void*)(xb + (wave + NW * (pc - GW)) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const GLB void*)(xsrc[pc - GW] + kt * (LAYOUT == 2 ? BM * 64 : BK)), (LDS void*)(xb + (wave + NW * (pc - GW)) * 1024), 16, 0, 0);
   };
   auto load_stage = [&](int kt) {
 #pragma unroll
@@ -182,16 +204,17 @@ __global__ __launch_bounds__(512) void kloop(const bf16* __restrict__ X, int64_t
 static const bf16 *dX, *dW;
 static unsigned long long* dclk;
 static float* dsink;
-constexpr int M = 16384, K = 3072, N = 768;
+constexpr int M = 16384, N = 768;
+static int K = 3072;
 
-template <int MODE, int SCHED, int BN>
+template <int MODE, int SCHED, int BN, int LAYOUT = 0, int PF = 0>
 void run(const char* what) {
   const int tiles_n = N / BN, nwg = (M / 256) * tiles_n;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int w = 0; w < 3; ++w) kloop<MODE, SCHED, BN><<<nwg, 512>>>(dX, K, dW, K, K, tiles_n, dclk, dsink);
+  for (int w = 0; w < 3; ++w) kloop<MODE, SCHED, BN, LAYOUT, PF><<<nwg, PF ? 576 : 512>>>(dX, K, dW, K, K, tiles_n, dclk, dsink);
   (void)hipEventRecord(e0);
   const int reps = 10;
-  for (int w = 0; w < reps; ++w) kloop<MODE, SCHED, BN><<<nwg, 512>>>(dX, K, dW, K, K, tiles_n, dclk, dsink);
+  for (int w = 0; w < reps; ++w) kloop<MODE, SCHED, BN, LAYOUT, PF><<<nwg, PF ? 576 : 512>>>(dX, K, dW, K, K, tiles_n, dclk, dsink);
   (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h(nwg);
@@ -200,12 +223,12 @@ void run(const char* what) {
   cyc /= nwg;
   const double per_stage = cyc / (K / 64);
   const double mf = 256.0 * BN * 64 * 2 / 4;   // flops per stage per SIMD -> MFMA cycles = flops / 1024
-  printf("%-58s BN %3d: %7.0f cycles/stage (MFMA alone %4.0f)  %7.1f us/launch  %6.1f TFLOP/s\n", what, BN, per_stage,
+  printf("K %4d %-58s BN %3d: %7.0f cycles/stage (MFMA alone %4.0f)  %7.1f us/launch  %6.1f TFLOP/s\n", K, what, BN, per_stage,
          mf / 1024.0, ms * 1e3 / reps, (MODE & 4) ? 2.0 * M * N * K / (ms * 1e-3 / reps) * 1e-12 : 0.0);
 }
 
 int main() {
-  std::vector<uint16_t> hx((size_t)M * K), hw((size_t)N * K);
+  std::vector<uint16_t> hx((size_t)M * 3072), hw((size_t)N * 3072);
   unsigned s = 12345;
   for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3c00 + ((s >> 9) & 0x3ff) | ((s >> 3) & 0x8000)); }
   for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = (uint16_t)(0x3800 + ((s >> 9) & 0x3ff) | ((s >> 3) & 0x8000)); }
@@ -226,5 +249,14 @@ int main() {
   run<7, 0, 128>("all: 256x128 tile, two stages");
   run<7, 2, 128>("all: 256x128 tile, three stages, spread");
   run<5, 2, 128>("MFMA + loads: 256x128, three stages, spread");
+  run<1, 0, 192, 0, 2>("loads only + L2 warmer wave 2 stages ahead");
+  run<1, 0, 192, 0, 4>("loads only + L2 warmer wave 4 stages ahead");
+  run<7, 0, 192, 0, 2>("all + L2 warmer 2 ahead");
+  run<7, 0, 192, 0, 3>("all + L2 warmer 3 ahead");
+  run<7, 0, 192, 0, 4>("all + L2 warmer 4 ahead");
+  run<7, 0, 192, 0, 6>("all + L2 warmer 6 ahead");
+  K = 768;
+  run<7, 0, 192>("all");
+  run<7, 0, 192, 0, 3>("all + L2 warmer 3 ahead");
   return 0;
 }
