@@ -243,6 +243,25 @@ typedef struct vy_transpose_desc {
 int vy_transpose_batched(const vy_transpose_desc* descs_dev, int32_t n, int32_t total_tiles, int dtype,
                          void* stream);
 
+/* Sampling front end of the generate loops.
+ * vy_greedy_step replaces reference models/decoder.py:478-507 (topk(k=1), the where() that forces prompt
+ *   tokens, the token write, the isin()/or of the EOS bookkeeping and the all() reduction) for one
+ *   generated position: for row b, next = argmax_v logits[b,v] (lowest index among equal maxima) unless
+ *   text_mask[b,cur_pos] != 0 (the row is still inside its prompt), then next = tokens[b,cur_pos];
+ *   tokens[b,cur_pos] = next; eos_reached[b] |= !forced && next in eos_ids[0..n_eos); *not_done (may be
+ *   NULL; zeroed by the caller) += number of rows with eos_reached[b] == 0 afterwards.
+ * vy_sampling_probs replaces reference logits_processors.py LogitsProcessor.__call__ for the five
+ *   processors: probs = softmax(mask(logits) / temperature) in fp32.  top_k > 0 keeps the values >= the
+ *   k-th largest (:59-63); 0 < top_p < 1 keeps the descending-sorted prefix up to and including the first
+ *   element whose cumulative softmax of the unscaled, top-k-masked logits exceeds top_p (:73-81, :92-102);
+ *   masked entries get probability exactly 0 (the reference writes -1e20 into them).  Equal logits at
+ *   the nucleus cut are all kept (the reference keeps an implementation-defined subset of a tie). */
+int vy_greedy_step(const void* logits, int64_t ldl, int64_t B, int64_t V, int dtype, int64_t* tokens,
+                   int64_t ldt, int64_t cur_pos, const uint8_t* text_mask, int64_t ldm,
+                   const int64_t* eos_ids, int32_t n_eos, uint8_t* eos_reached, int32_t* not_done, void* stream);
+int vy_sampling_probs(const void* logits, int64_t ldl, int64_t B, int64_t V, int dtype, float temperature,
+                      int32_t top_k, float top_p, float* probs, int64_t ldp, void* stream);
+
 /* y = x converted between fp32 and bf16 (n elements). src_dtype -> dst_dtype. */
 int vy_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 

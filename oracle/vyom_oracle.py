@@ -663,3 +663,95 @@ def clm_loss(logits: Tensor, labels: Tensor) -> Tensor:
     lg = logits[:, :-1].reshape(-1, logits.shape[-1]).float()
     lb = labels[:, 1:].reshape(-1)
     return torch.nn.functional.cross_entropy(lg, lb, ignore_index=-100)
+
+
+# ----------------------------------------------------------------------------
+# sampling processors and speculative decoding
+# ----------------------------------------------------------------------------
+
+
+def processor_masked_logits(logits: Tensor, top_k: int = 0, top_p: float = 0.0) -> Tensor:
+    """``_process`` of Greedy/Multinomial (identity), TopK (logits_processors.py:59-63), Nucleus (:73-81)
+    and TopKNucleus (:92-102) on a COPY of ``logits``: removed entries become -1e20."""
+    logits = logits.clone()
+    if top_k:
+        k = min(top_k, logits.size(-1))
+        kth = torch.topk(logits, k, dim=-1)[0][..., -1, None]
+        logits[logits < kth] = -1e20
+    if top_p:
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        cumulative = torch.cumsum(torch.softmax(sorted_logits, dim=-1), dim=-1)
+        remove = cumulative > top_p
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = 0
+        sorted_logits[remove] = -1e20
+        logits = torch.gather(sorted_logits, -1, sorted_indices.argsort(-1))
+    return logits
+
+
+def processor_probs(logits: Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 0.0) -> Tensor:
+    """LogitsProcessor.__call__ (logits_processors.py:13-16): softmax(_process(logits) / temperature)."""
+    return torch.softmax(processor_masked_logits(logits, top_k, top_p) / temperature, dim=-1)
+
+
+def speculative_norm(x: Tensor) -> Tensor:
+    """speculative_decoding.py:73-83."""
+    x_max = torch.where(x > 0, x, torch.zeros_like(x))
+    return x_max / torch.sum(x_max, dim=-1, keepdim=True)
+
+
+def speculative_generate(inputs: Tensor, drafter_logits, target_logits, vocab_size: int, max_seq_length: int,
+                         rand_fn, gamma: int = 5, temperature: float = 1.0, top_k: int = 0, top_p: float = 0.0,
+                         max_gen_len: int = 128, eos_tokens_id=2, pad_token_id: int = 2,
+                         skip_sample_adjustment: bool = False, first_target: bool = True):
+    """speculative_decoding.py:86-245 with argmax sampling (GreedyProcessor.sample, logits_processors.py:35-36)
+    and without a KV cache (use_cache=False: each call recomputes its prefix).  ``*_logits(ids)`` -> (1, L, V)
+    logits of a model on the prefix ``ids``; ``rand_fn(n)`` -> the n acceptance draws of a round (:200)."""
+    proc = lambda l: processor_probs(l, temperature, top_k, top_p)   # noqa: E731
+    sample = lambda p: torch.argmax(p, dim=-1).unsqueeze(-1)          # noqa: E731
+    stops = eos_tokens_id if isinstance(eos_tokens_id, list) else [eos_tokens_id]
+    stop_tokens = torch.tensor(stops, dtype=torch.long).unsqueeze(1)
+    accepted, speculated = .0, .0
+    prompt_len = len(inputs[0])
+    total_len = min(max_seq_length, prompt_len + max_gen_len)
+    ids = torch.full((1, total_len), pad_token_id, dtype=torch.long)
+    ids[0, :prompt_len] = inputs
+    cur = prompt_len
+    if first_target:   # :148-162
+        t = sample(proc(target_logits(ids[..., :cur])[..., -1, :]))
+        ids[0, cur] = t
+        cur += 1
+        if torch.isin(t, stop_tokens):
+            return ids[0, prompt_len:cur].tolist(), 0
+    while cur < total_len:
+        g = min(gamma, total_len - cur - 1)
+        q = torch.zeros((1, g, vocab_size))
+        for k in range(g):   # :172-185
+            dp = proc(drafter_logits(ids[..., :cur + k])[..., -1, :])
+            q[0, k] = dp
+            ids[0, cur + k] = sample(dp)
+        speculated += g
+        mp = target_logits(ids[..., :cur + g])   # :189-197
+        p = proc(mp[..., cur - 1:cur + g - 1, :])
+        r = rand_fn(g)
+        fractions = p / q
+        n = g
+        for i in range(g):   # :200-206
+            if r[i] > fractions[0, i, ids[0, cur + i]]:
+                n = i
+                break
+        accepted += n
+        loc = torch.nonzero(torch.eq(ids[..., cur:cur + n], stop_tokens))   # :211-216
+        if loc.shape[0] > 0:
+            return ids[0, prompt_len:cur + loc[0, 1].item() + 1].tolist(), accepted / speculated
+        if n == g:   # :219-221
+            p_p = proc(mp[..., cur + g - 1, :])
+        else:        # :228-231
+            p_p = p[..., n, :] if skip_sample_adjustment else speculative_norm(p[..., n, :] - q[0, n, :])
+        x = sample(p_p)
+        ids[0, cur + n:cur + g] = pad_token_id
+        ids[0, cur + n] = x
+        cur += n + 1
+        if torch.isin(x, stop_tokens):
+            return ids[0, prompt_len:cur].tolist(), accepted / speculated
+    return ids[0, prompt_len:].tolist(), accepted / speculated

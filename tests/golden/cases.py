@@ -256,3 +256,43 @@ def gemma_layer_shapes(p=""):
             f"{p}self_attn.v_proj.weight": (hk * dh, d), f"{p}self_attn.o_proj.weight": (d, h * dh),
             f"{p}mlp.gate_proj.weight": (i, d), f"{p}mlp.up_proj.weight": (i, d), f"{p}mlp.down_proj.weight": (d, i),
             f"{p}input_layernorm.weight": (d,), f"{p}post_attention_layernorm.weight": (d,)}
+
+
+# ---- sampling processors / speculative decoding ----------------------------------
+
+def sampling_logits() -> np.ndarray:
+    """(3, 1531) fp32 logits: row 0 flat-ish, row 1 peaked, row 2 wide."""
+    from vyomai_amd import recipe
+    x = recipe.uniform("samp.logits", (3, 1531))
+    return (x * np.array([[1.5], [9.0], [4.0]], dtype=np.float32)).astype(np.float32)
+
+
+# name -> (reference class, constructor args)
+PROCESSORS = {
+    "greedy": ("GreedyProcessor", (1,)),
+    "multinomial_t07": ("MultinomialProcessor", (0.7,)),
+    "topk50_t08": ("TopKProcessor", (0.8, 50)),
+    "topk_all": ("TopKProcessor", (1.0, 5000)),
+    "nucleus09_t02": ("NucleusProcessor", (0.2, 0.9)),
+    "nucleus05_t1": ("NucleusProcessor", (1.0, 0.5)),
+    "topk40_nucleus08_t09": ("TopKNucleusProcessor", (0.9, 40, 0.8)),
+}
+
+
+def speculative_draws() -> np.ndarray:
+    """The uniform [0,1) numbers the acceptance test consumes, in order."""
+    from vyomai_amd import recipe
+    return (recipe.uniform("spec.rand", (512,)) * 0.5 + 0.5).astype(np.float32)
+
+
+SPECULATIVE = {
+    # a small drafter against a deeper target: accepts and rejects mixed
+    "mixed": dict(target_layers=3, drafter_layers=1, drafter_prefix="spec.drafter.", prompt_len=6, gamma=4,
+                  max_gen_len=18, eos=2, skip=False, first_target=True, processor=("GreedyProcessor", (1,))),
+    # the drafter IS the target (same weights): every draft is accepted
+    "same": dict(target_layers=2, drafter_layers=2, drafter_prefix="spec.target.", prompt_len=5, gamma=3,
+                 max_gen_len=11, eos=2, skip=False, first_target=True, processor=("GreedyProcessor", (1,))),
+    # no target prefill, no sample adjustment, temperature != 1, two stop tokens
+    "plain": dict(target_layers=2, drafter_layers=1, drafter_prefix="spec.drafter.", prompt_len=7, gamma=5,
+                  max_gen_len=14, eos=[2, 7], skip=True, first_target=False, processor=("GreedyProcessor", (0.7,))),
+}

@@ -332,8 +332,71 @@ def paligemma_blocks():
     save("paligemma_blocks", **{k: cases.sub2(v.reshape(-1, v.shape[-1])) if v.numel() > 20000 else v for k, v in out.items()})
 
 
+# ---------------------------------------------------------------------------
+# G. sampling processors and speculative decoding
+# ---------------------------------------------------------------------------
+
+
+def sampling():
+    import types
+    from VyomAI import logits_processors as ref_lp
+    from VyomAI import speculative_decoding as ref_sd
+
+    out = {}
+    logits = T(cases.sampling_logits())
+    for name, (cls, args) in cases.PROCESSORS.items():
+        proc = getattr(ref_lp, cls)(*args)
+        out[f"proc.{name}.probs"] = proc(logits.clone())
+        out[f"proc.{name}.masked"] = proc._process(logits.clone())
+        out[f"proc.{name}.argmax"] = ref_lp.GreedyProcessor.sample(proc, proc(logits.clone()))
+
+    class HFLike(torch.nn.Module):
+        """What speculative_generate expects of a model (speculative_decoding.py:150-154), around the
+        reference's own DecoderModel; use_cache=False semantics (the prefix is recomputed)."""
+
+        def __init__(self, m):
+            super().__init__()
+            self.m, self.config, self.device = m, m.config, torch.device("cpu")
+
+        def forward(self, input_ids, past_key_values=None, use_cache=False):
+            o = self.m(input_ids, torch.ones_like(input_ids))
+            return types.SimpleNamespace(logits=o.logits, past_key_values=past_key_values)
+
+    draws = T(cases.speculative_draws())
+    real_rand = torch.rand
+    for name, c in cases.SPECULATIVE.items():
+        tcfg = cases.with_kv(cases.test_cfg(), None)
+        tcfg.num_hidden_layers = c["target_layers"]
+        dcfg = cases.with_kv(cases.test_cfg(), None)
+        dcfg.num_hidden_layers = c["drafter_layers"]
+        target = HFLike(filled(ref_dec.DecoderModel(tcfg, "rope", None), "spec.target."))
+        drafter = HFLike(filled(ref_dec.DecoderModel(dcfg, "rope", None), c["drafter_prefix"]))
+        prompt = T(recipe.token_ids("spec.prompt", (1, c["prompt_len"]), 3, tcfg.vocab_size))
+        state = {"i": 0}
+
+        def fixed_rand(n, device=None):   # the acceptance draws of speculative_decoding.py:200, made reproducible
+            a = draws[state["i"]:state["i"] + n].clone()
+            state["i"] += n
+            return a
+
+        torch.rand = fixed_rand
+        try:
+            cls, args = c["processor"]
+            ids, rate = ref_sd.speculative_generate(
+                prompt, drafter, target, gamma=c["gamma"], logits_processor=getattr(ref_lp, cls)(*args),
+                max_gen_len=c["max_gen_len"], eos_tokens_id=c["eos"], pad_token_id=2, use_cache=False,
+                skip_sample_adjustment=c["skip"], first_target=c["first_target"])
+        finally:
+            torch.rand = real_rand
+        out[f"spec.{name}.ids"] = np.array(ids, dtype=np.int64)
+        out[f"spec.{name}.rate"] = np.array([rate], dtype=np.float64)
+        out[f"spec.{name}.draws_used"] = np.array([state["i"]], dtype=np.int64)
+        print(name, len(ids), rate, state["i"])
+    save("sampling", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["modules", "models", "grads", "paligemma", "seq2seq"]
+    which = sys.argv[1:] or ["modules", "models", "grads", "paligemma", "seq2seq", "sampling"]
     if "modules" in which:
         module_level()
     if "models" in which:
@@ -344,3 +407,5 @@ if __name__ == "__main__":
         paligemma_blocks()
     if "seq2seq" in which:
         seq2seq()
+    if "sampling" in which:
+        sampling()

@@ -292,3 +292,54 @@ def test_paligemma_blocks(golden):
     w = T(recipe.param_value("pg.norm.weight", (G["hidden_size"],)))
     y = O.rms_norm_gemma(xg, w, G["rms_norm_eps"])
     close(cases.sub2(y.reshape(-1, y.shape[-1])), g["gemma.rmsnorm"], 2e-6, "rmsnorm")
+
+
+# ---- sampling processors and speculative decoding --------------------------------
+
+def _proc_args(cls, args):
+    """(temperature, top_k, top_p) of a reference processor constructor call."""
+    if cls in ("GreedyProcessor", "MultinomialProcessor"):
+        return float(args[0]), 0, 0.0
+    if cls == "TopKProcessor":
+        return float(args[0]), int(args[1]), 0.0
+    if cls == "NucleusProcessor":
+        return float(args[0]), 0, float(args[1])
+    return float(args[0]), int(args[1]), float(args[2])
+
+
+@pytest.mark.parametrize("name", list(cases.PROCESSORS))
+def test_sampling_processors(golden, name):
+    g = golden("sampling")
+    logits = T(cases.sampling_logits())
+    t, k, p = _proc_args(*cases.PROCESSORS[name])
+    assert np.array_equal(O.processor_masked_logits(logits, k, p).numpy(), g[f"proc.{name}.masked"])
+    probs = O.processor_probs(logits, t, k, p)
+    close(probs, g[f"proc.{name}.probs"], 1e-7, name)
+    assert np.array_equal(torch.argmax(probs, -1).unsqueeze(-1).numpy(), g[f"proc.{name}.argmax"])
+
+
+@pytest.mark.parametrize("name", list(cases.SPECULATIVE))
+def test_speculative_decoding(golden, name):
+    g = golden("sampling")
+    c = cases.SPECULATIVE[name]
+    tcfg, dcfg = cases.with_kv(cases.test_cfg(), None), cases.with_kv(cases.test_cfg(), None)
+    tcfg.num_hidden_layers, dcfg.num_hidden_layers = c["target_layers"], c["drafter_layers"]
+    tsd = sd_from(cases.text_model_shapes(tcfg, "rope", None, head=True), "spec.target.")
+    dsd = sd_from(cases.text_model_shapes(dcfg, "rope", None, head=True), c["drafter_prefix"])
+    tl = lambda ids: O.decoder_forward(tsd, O.Cfg.of(tcfg), ids, torch.ones_like(ids), "rope").logits
+    dl = lambda ids: O.decoder_forward(dsd, O.Cfg.of(dcfg), ids, torch.ones_like(ids), "rope").logits
+    draws, used = T(cases.speculative_draws()), [0]
+
+    def rand_fn(n):
+        used[0] += n
+        return draws[used[0] - n:used[0]]
+
+    prompt = T(recipe.token_ids("spec.prompt", (1, c["prompt_len"]), 3, tcfg.vocab_size))
+    t, k, p = _proc_args(*c["processor"])
+    ids, rate = O.speculative_generate(prompt, dl, tl, tcfg.vocab_size, tcfg.max_position_embeddings, rand_fn,
+                                       gamma=c["gamma"], temperature=t, top_k=k, top_p=p, max_gen_len=c["max_gen_len"],
+                                       eos_tokens_id=c["eos"], pad_token_id=2, skip_sample_adjustment=c["skip"],
+                                       first_target=c["first_target"])
+    assert ids == g[f"spec.{name}.ids"].tolist()
+    assert abs(rate - float(g[f"spec.{name}.rate"][0])) < 1e-12
+    assert used[0] == int(g[f"spec.{name}.draws_used"][0])

@@ -93,9 +93,28 @@ __global__ __launch_bounds__(PF ? 576 : 512) void kloop(const bf16* __restrict__
     else
       __builtin_amdgcn_global_load_lds((const GLB void*)(xsrc[pc - GW] + kt * (LAYOUT == 2 ? BM * 64 : BK)), (LDS void*)(xb + (wave + NW * (pc - GW)) * 1024), 16, 0, 0);
   };
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  f32x4 sreg[GX + GW];
   auto load_stage = [&](int kt) {
+    if (SCHED == 4 || SCHED == 5) {   // register path
+#pragma unroll
+      for (int pc = 0; pc < GX + GW; ++pc) {
+        const bf16* sp = pc < GW ? wsrc[pc] + kt * BK : xsrc[pc - GW] + kt * BK;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(sreg[pc]) : "v"(sp) : "memory");
+      }
+      return;
+    }
 #pragma unroll
     for (int pc = 0; pc < GX + GW; ++pc) load_piece(kt, pc);
+  };
+  auto store_stage = [&](int kt) {
+    const unsigned xb = lds_addr(smem) + (kt % NS) * STAGE + wave * 1024 + lane * 16;
+    const unsigned wb = xb + BM * ROWB;
+#pragma unroll
+    for (int pc = 0; pc < GX + GW; ++pc) {
+      const unsigned a = pc < GW ? wb + NW * pc * 1024 : xb + NW * (pc - GW) * 1024;
+      asm volatile("ds_write_b128 %0, %1" ::"v"(a), "v"(sreg[pc]) : "memory");
+    }
   };
 
   f32x16 acc[TN][TM];
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(PF ? 576 : 512) void kloop(const bf16* __restrict__
     const int ahead = NS - 1;                       // stage issued during stage kt
     const bool more = kt + ahead < KT;
     const bool late = SCHED == 3 && wave >= 4;
-    if (LOADS && more && SCHED == 0) load_stage(kt + ahead);
+    if (LOADS && more && (SCHED == 0 || SCHED == 4 || SCHED == 5)) load_stage(kt + ahead);
     if (LOADS && more && SCHED == 3 && !late) load_stage(kt + ahead);
     const unsigned boff = buf * STAGE;
 #pragma unroll
@@ -177,6 +196,7 @@ __global__ __launch_bounds__(PF ? 576 : 512) void kloop(const bf16* __restrict__
           if (pc >= lo && pc < hi) load_piece(kt + ahead, pc);
       }
       if (LOADS && more && late && ks == 2) load_stage(kt + ahead);
+      if (LOADS && more && SCHED == 5 && ks == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); store_stage(kt + ahead); }
       if (ks < 3) {
         read_frags(wa[ks + 1] + boff, xa[ks + 1] + boff, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
         if (READS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
@@ -197,6 +217,10 @@ __global__ __launch_bounds__(PF ? 576 : 512) void kloop(const bf16* __restrict__
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < TN; ++i) s += acc[i][0][0] + acc[i][1][3];
+  if (SCHED == 4 || SCHED == 5) {
+#pragma unroll
+    for (int pc = 0; pc < GX + GW; ++pc) s += sreg[pc][0];
+  }
   if (s == 12345.678f) sink[0] = s;
   if (tid == 0) clk[blockIdx.x] = t1 - t0;
 }
@@ -249,14 +273,9 @@ int main() {
   run<7, 0, 128>("all: 256x128 tile, two stages");
   run<7, 2, 128>("all: 256x128 tile, three stages, spread");
   run<5, 2, 128>("MFMA + loads: 256x128, three stages, spread");
-  run<1, 0, 192, 0, 2>("loads only + L2 warmer wave 2 stages ahead");
-  run<1, 0, 192, 0, 4>("loads only + L2 warmer wave 4 stages ahead");
-  run<7, 0, 192, 0, 2>("all + L2 warmer 2 ahead");
-  run<7, 0, 192, 0, 3>("all + L2 warmer 3 ahead");
-  run<7, 0, 192, 0, 4>("all + L2 warmer 4 ahead");
-  run<7, 0, 192, 0, 6>("all + L2 warmer 6 ahead");
-  K = 768;
-  run<7, 0, 192>("all");
-  run<7, 0, 192, 0, 3>("all + L2 warmer 3 ahead");
+  run<1, 4, 192>("loads only, global_load_dwordx4 into registers (no LDS write)");
+  run<1, 5, 192>("loads only, register path + ds_write_b128");
+  run<5, 4, 192>("MFMA + register loads (no LDS write)");
+  run<7, 5, 192>("all, register path + ds_write_b128 after k-step 2");
   return 0;
 }

@@ -11,3 +11,6 @@ from .models.vision_encoder import Vit  # noqa: F401
 from .models.multimodel import VisionLanguageModel  # noqa: F401
 from .models.encoder_decoder import EncoderDecoderModel  # noqa: F401
 from .generation_utils import generate, generate_multimodel, generate_seq2seq  # noqa: F401
+from .logits_processors import (LogitsProcessor, GreedyProcessor, MultinomialProcessor, TopKProcessor,  # noqa: F401
+                                NucleusProcessor, TopKNucleusProcessor)
+from .speculative_decoding import speculative_generate  # noqa: F401

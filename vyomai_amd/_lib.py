@@ -50,6 +50,8 @@ PROTOTYPES = {
     "vy_embedding_fwd": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i, _p],
     "vy_embedding_bwd": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p],
     "vy_transpose": [_p, _i64, _p, _i64, _i64, _i64, _i, _p],
+    "vy_greedy_step": [_p, _i64, _i64, _i64, _i, _p, _i64, _i64, _p, _i64, _p, _i, _p, _p, _p],
+    "vy_sampling_probs": [_p, _i64, _i64, _i64, _i, _f, _i, _f, _p, _i64, _p],
     "vy_decoder_step": [_p, _p, _i64, _p, _p, _p, _i64, _p],
     "vy_cast": [_p, _p, _i64, _i, _i, _p],
 }

@@ -13,7 +13,7 @@ void vy_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vy_last_error(void) { return g_err; }
-extern "C" int vy_abi_version(void) { return 3; }
+extern "C" int vy_abi_version(void) { return 4; }
 
 namespace {
 

@@ -10,6 +10,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..layers.attention import _SelfAttentionBase
 from ..layers.ffn import FeedForward
 from ..layers.kv_cache import DynamicCacheOne, StaticCacheOne
@@ -167,7 +168,23 @@ class DecoderModel(nn.Module, PositionMixin):
         eos_reached = torch.zeros(bsz, dtype=torch.bool, device=device)
         input_text_mask = tokens != pad_id
         stop_tokens = torch.tensor(getattr(self.config, "eos_token_id", 2), device=device)
+        # greedy: one kernel per position does the top-1, the prompt forcing, the token write and the EOS
+        # bookkeeping (vy_greedy_step) and counts the rows still running; the host reads that count one
+        # step late from pinned memory, so a step is always queued behind the running one.
+        greedy = not do_sample
+        if greedy:
+            stop_ids = stop_tokens.reshape(-1).to(torch.long).contiguous()
+            not_done = torch.zeros(total, dtype=torch.int32, device=device)
+            done_host = torch.empty(total, dtype=torch.int32).pin_memory()
+            landed = {}
         for cur_pos in range(prompt_len, total):
+            if greedy and cur_pos - 2 in landed:
+                landed.pop(cur_pos - 2).synchronize()
+                if int(done_host[cur_pos - 2]) == 0:
+                    # every row had reached EOS after position cur_pos-2: the reference stops there (:512-513);
+                    # position cur_pos-1 was generated in the meantime and goes back to padding
+                    tokens[:, cur_pos - 1] = pad_id
+                    return tokens
             if use_cache and use_static_cache and cur_pos - prev_pos == 1 and device.type == "cuda":
                 if plan is None:
                     from ..decode_plan import DecodePlan
@@ -175,27 +192,38 @@ class DecoderModel(nn.Module, PositionMixin):
                                       device)
                 hidden = self._embed(self.word_embeddings, tokens[:, prev_pos:cur_pos])
                 hidden, _ = self._positions(hidden, prev_pos, 1)
-                logits, _ = plan.step(hidden[:, 0, :].contiguous(), prev_pos)
-                next_token_logits = logits / temperature
+                next_token_logits, _ = plan.step(hidden[:, 0, :].contiguous(), prev_pos)
             else:
                 # only the last position's logits are used (reference :478-489 slices them out of the full
                 # (B, L, V) tensor): the vocabulary projection runs on that one row per sequence
                 hidden, kv_cache = self.forward_hidden(tokens[:, prev_pos:cur_pos], attention_mask, use_cache,
                                                        kv_cache, prev_pos)
-                next_token_logits = self.lm_head(hidden[:, -1:, :].contiguous())[:, -1] / temperature
-            if do_sample:
-                # the reference samples from the raw logits (:491-492); kept
-                next_token = torch.multinomial(next_token_logits.float(), num_samples=1)
+                next_token_logits = self.lm_head(hidden[:, -1:, :].contiguous())[:, -1]
+            if greedy:
+                # (the division by the temperature does not move the maximum)
+                ops.greedy_step_(next_token_logits, tokens, cur_pos, input_text_mask, stop_ids, eos_reached,
+                                 not_done[cur_pos:cur_pos + 1])
+                done_host[cur_pos:cur_pos + 1].copy_(not_done[cur_pos:cur_pos + 1], non_blocking=True)
+                landed[cur_pos] = torch.cuda.Event()
+                landed[cur_pos].record()
             else:
-                _, next_token = torch.topk(next_token_logits, k=1, dim=-1)
-            next_token = next_token.reshape(-1)
-            next_token = torch.where(input_text_mask[:, cur_pos], tokens[:, cur_pos], next_token)
-            tokens[:, cur_pos] = next_token
-            eos_reached |= (~input_text_mask[:, cur_pos]) & torch.isin(next_token, stop_tokens)
+                # the reference samples from the raw logits (:491-492); kept
+                next_token = torch.multinomial((next_token_logits / temperature).float(), num_samples=1).reshape(-1)
+                next_token = torch.where(input_text_mask[:, cur_pos], tokens[:, cur_pos], next_token)
+                tokens[:, cur_pos] = next_token
+                eos_reached |= (~input_text_mask[:, cur_pos]) & torch.isin(next_token, stop_tokens)
             if use_cache:
                 prev_pos = cur_pos
-            attention_mask = torch.cat(
-                [attention_mask, torch.ones((bsz, 1), device=device, dtype=attention_mask.dtype)], dim=-1)
-            if bool(eos_reached.all()):
+            if plan is None:
+                attention_mask = torch.cat(
+                    [attention_mask, torch.ones((bsz, 1), device=device, dtype=attention_mask.dtype)], dim=-1)
+            if not greedy and bool(eos_reached.all()):
                 break
+        if greedy:
+            # the last two positions have not been looked at yet
+            torch.cuda.current_stream().synchronize()
+            for pos in sorted(landed):
+                if int(done_host[pos]) == 0:
+                    tokens[:, pos + 1:] = pad_id
+                    break
         return tokens

@@ -349,6 +349,41 @@ def embedding(table: Tensor, ids: Tensor, err_flag: Optional[Tensor] = None) -> 
     return out
 
 
+def greedy_step_(logits: Tensor, tokens: Tensor, cur_pos: int, text_mask: Optional[Tensor], eos_ids: Tensor,
+                 eos_reached: Tensor, not_done: Optional[Tensor] = None) -> None:
+    """One generated position of the greedy loop (vy_greedy_step): tokens[:, cur_pos] <- forced prompt token or
+    argmax(logits); eos_reached |= new EOS; not_done (one int32) += rows still running."""
+    _need_gpu(logits, tokens, text_mask, eos_ids, eos_reached, not_done)
+    assert logits.dim() == 2 and logits.stride(1) == 1 and tokens.dtype == torch.long and tokens.stride(1) == 1
+    assert eos_reached.dtype in (torch.bool, torch.uint8) and eos_reached.is_contiguous()
+    assert eos_ids.dtype == torch.long and eos_ids.is_contiguous()
+    B, V = logits.shape
+    assert tokens.shape[0] == B and eos_reached.numel() == B and 0 <= cur_pos < tokens.shape[1]
+    if text_mask is not None:
+        assert text_mask.dtype in (torch.bool, torch.uint8) and text_mask.stride(1) == 1 and text_mask.shape == tokens.shape
+    if not_done is not None:
+        assert not_done.dtype == torch.int32 and not_done.numel() == 1
+    call("vy_greedy_step", logits.data_ptr(), logits.stride(0), B, V, dtype_code(logits.dtype), tokens.data_ptr(),
+         tokens.stride(0), int(cur_pos), _ptr(text_mask), 0 if text_mask is None else text_mask.stride(0),
+         eos_ids.data_ptr(), eos_ids.numel(), eos_reached.data_ptr(), _ptr(not_done), _stream())
+
+
+def sampling_probs(logits: Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 0.0) -> Tensor:
+    """fp32 softmax(mask(logits) / temperature) over the last dimension (vy_sampling_probs):
+    top_k > 0 and 0 < top_p < 1 mask as TopKProcessor / NucleusProcessor of the reference do."""
+    _need_gpu(logits)
+    V = logits.shape[-1]
+    l2 = logits.reshape(-1, V)
+    if l2.stride(1) != 1:
+        l2 = l2.contiguous()
+    probs = torch.empty((l2.shape[0], V), dtype=torch.float32, device=logits.device)
+    if l2.shape[0] == 0:   # no rows (the last round of speculative decoding verifies zero drafts)
+        return probs.view(*logits.shape)
+    call("vy_sampling_probs", l2.data_ptr(), l2.stride(0), l2.shape[0], V, dtype_code(l2.dtype), float(temperature),
+         int(top_k), float(top_p), probs.data_ptr(), probs.stride(0), _stream())
+    return probs.view(*logits.shape)
+
+
 def embedding_bwd_(dout: Tensor, ids: Tensor, dw: Tensor, padding_idx: Optional[int]) -> None:
     """dw[ids[m], :] += dout[m, :] in fp32, skipping padding_idx  (vy_embedding_bwd)."""
     _need_gpu(dout, ids, dw)
