@@ -8,7 +8,7 @@ from vyomai_amd import ops, _lib
 from tools.bench_kernels import timeit
 
 def read():
-    out = (C.c_ulonglong * 3)()
+    out = (C.c_ulonglong * 6)()
     torch.cuda.synchronize()
     assert _lib.load().vy_debug_gemm_clock(out) == 0
     cyc, ticks, n = out[0], out[1], out[2]

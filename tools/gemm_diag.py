@@ -8,16 +8,17 @@ from tools.bench_kernels import timeit
 import ctypes as C
 from vyomai_amd import _lib
 def clock():
-    out = (C.c_ulonglong * 3)()
+    out = (C.c_ulonglong * 6)()
     torch.cuda.synchronize()
     _lib.load().vy_debug_gemm_clock(out)
-    return (out[0] / (out[1] / 100.0) if out[1] else 0.0), (out[0] / out[2] if out[2] else 0.0)
+    n = max(out[2], 1)
+    return (out[0] / (out[1] / 100.0) if out[1] else 0.0), (out[0] / n), [out[3] / n, out[4] / n, out[5] / n]
 M = 16384
 bf = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g).to(bf).cuda()
 line = [f"mask={os.environ.get('VY_GEMM_ROT', '0'):>2s} data={os.environ.get('DATA', 'randn'):6s}"]
-for N, K in ((768, 768), (768, 3072), (768, 12288), (2304, 768), (3072, 768)):
+for N, K in ((768, 768), (768, 3072), (2304, 768), (3072, 768)):
     x, w, b = r(M, K), (r(N, K) / K ** 0.5).contiguous(), r(N)
     mode = os.environ.get("DATA", "randn")      # operand values: the matrix pipe is throttled by toggling
     if mode == "zeros":
@@ -28,7 +29,8 @@ for N, K in ((768, 768), (768, 3072), (768, 12288), (2304, 768), (3072, 768)):
         x = x.sign(); w = w.sign() / K
     out = torch.empty(M, N, dtype=bf, device="cuda")
     clock()
-    t0 = timeit(lambda: ops.linear(x, w, b, out=out), 20)
-    mhz, cyc = clock()
-    line.append(f"N{N}K{K}: {t0:6.1f}us" + (f" {mhz:4.0f}MHz {cyc/1e3:5.1f}kcyc" if mhz else ""))
+    res = r(M, N) if os.environ.get("RES") else None
+    t0 = timeit(lambda: ops.linear(x, w, b, residual=res, out=out), 20)
+    mhz, cyc, parts = clock()
+    line.append(f"N{N}K{K}: {t0:6.1f}us" + (f" {mhz:4.0f}MHz {cyc/1e3:5.1f}kcyc (pro {parts[0]/1e3:.1f} loop {parts[1]/1e3:.1f} epi {parts[2]/1e3:.1f})" if mhz else ""))
 print("  ".join(line))

@@ -188,11 +188,17 @@ __device__ __forceinline__ void epi_qkv_quad(const EpiQkv<T>& e, float (&v)[4], 
 // measurement aid (VY_GEMM_ROT bit 16): workgroup 0 accumulates its shader-clock cycles (s_memtime)
 // and 100 MHz ticks (s_memrealtime) here; vy_debug_gemm_clock() reads and clears them
 // (tools/gemm_clock.py): cycles / ticks * 100 = the shader clock in MHz the GEMMs really ran at.
-__device__ unsigned long long vy_gemm_clk[3];
+__device__ unsigned long long vy_gemm_clk[6];   // cycles, ticks, launches, prologue / k-loop / epilogue cycles
 #define VY_CLK_BEGIN(on)                                                         \
   const bool clk_on_ = (on) && blockIdx.x == 0 && threadIdx.x == 0;              \
-  unsigned long long clk_c0_ = 0, clk_w0_ = 0;                                   \
-  if (clk_on_) { clk_c0_ = __builtin_readcyclecounter(); clk_w0_ = wall_clock64(); }
+  unsigned long long clk_c0_ = 0, clk_w0_ = 0, clk_m_ = 0;                       \
+  if (clk_on_) { clk_c0_ = clk_m_ = __builtin_readcyclecounter(); clk_w0_ = wall_clock64(); }
+#define VY_CLK_MARK(i)                                                           \
+  if (clk_on_) {                                                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter();                \
+    atomicAdd(&vy_gemm_clk[3 + (i)], now_ - clk_m_);                             \
+    clk_m_ = now_;                                                               \
+  }
 #define VY_CLK_END()                                                             \
   if (clk_on_) {                                                                 \
     atomicAdd(&vy_gemm_clk[0], __builtin_readcyclecounter() - clk_c0_);          \
@@ -670,6 +676,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  VY_CLK_MARK(0)
   read_frags(wa[0], xa[0], wf[0], xf[0]);
   int xbuf = 0;   // kt % 3
   for (int kt = 0; kt < KT; ++kt) {
@@ -700,7 +707,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
     xbuf = xbuf == 2 ? 0 : xbuf + 1;
     if (kt + 1 < KT) read_frags(wa[0] + (WT - wo), xa[0] + xbuf * XT, wf[0], xf[0]);
   }
+  VY_CLK_MARK(1)
   gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
+  VY_CLK_MARK(2)
   VY_CLK_END()
 }
 
@@ -1439,8 +1448,8 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
 int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N; }
 
 // measurement aid, not part of include/vyom_hip.h: {shader cycles, 10 ns ticks, launches} since the last call
-extern "C" int vy_debug_gemm_clock(unsigned long long* out3) {
-  unsigned long long z[3] = {0, 0, 0};
+extern "C" int vy_debug_gemm_clock(unsigned long long* out3) {   // out3: 6 values
+  unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(vy_gemm_clk), sizeof(z)) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(vy_gemm_clk), z, sizeof(z)) != hipSuccess;
 }
