@@ -818,11 +818,15 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   // (11.7 instead of 15.6 LDS-DMA bytes per kFLOP, still two workgroups per CU), 4 = the same, 3-deep ring
   // default 0.  5 = 32-row stages (32 KiB of LDS, three workgroups per CU, 720 work items on 768 slots
   // instead of 432 on 512): 6 % faster on the FFN shapes alone, no difference inside the training step
-  const int var = wv < 0 ? 0 : wv;
-  const int BNt = var == 1 ? 256 : 128, BKt = (var == 2 || var == 4) ? 256 : 128;
+  // default: 128 x 128; the vocabulary projection (N = 50265: every tile reduces all M rows, so the 256 KiB
+  // atomic epilogue of a 256 x 256 tile is paid once per 512 stages) takes the 256 x 256 ring: +9 %
+  const int var = wv < 0 ? (N >= 8192 && M >= 4096 ? 8 : 0) : wv;
+  const bool big = var == 7 || var == 8;   // 256 x 256, 32-row stages, 3- / 4-deep ring, one workgroup per CU
+  const int BNt = (var == 1 || big) ? 256 : 128, BKt = (var == 2 || var == 4 || big) ? 256 : 128;
   const int tiles_n = (int)vy_cdiv(N, BNt), tiles_k = (int)vy_cdiv(K, BKt);
   const int tiles = tiles_n * tiles_k;
   int64_t splits = vy_cdiv(tgt > 0 ? tgt : (var == 1 ? 256 : (var == 5 ? 704 : 384)), tiles);  // ~1.5 workgroups per CU
+  if (big && tgt <= 0) splits = 256 / tiles;                 // at most one round of 256 workgroups
   const int64_t max_splits = vy_cdiv(M, 256);                // >= 4 stages of 64 rows each
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -838,6 +842,8 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   else if (var == 4) WG_GO(128, 256, 32, 3);
   else if (var == 5) WG_GO(128, 128, 32, 2);   // 32 KiB of LDS: three workgroups per CU
   else if (var == 6) WG_GO(128, 128, 64, 0);   // dY three deep, X two deep: 80 KiB, two workgroups per CU
+  else if (var == 7) WG_GO(256, 256, 32, 3);   // 7.8 LDS-DMA bytes per kFLOP, 96 KiB
+  else if (var == 8) WG_GO(256, 256, 32, 4);   // ... 128 KiB
   else { if (ns == 3) WG_GO(128, 128, 64, 3); else WG_GO(128, 128, 64, 2); }
 #undef WG_GO
   VY_CHECK_LAUNCH(who);
