@@ -1,14 +1,12 @@
-"""Speculative decoding (Leviathan et al., arXiv 2211.17192) -- the reference's ``speculative_generate``
-(VyomAI/speculative_decoding.py:86-245) over vyomai_amd ``DecoderModel``s.
+"""Speculative decoding (Leviathan et al., arXiv 2211.17192) over vyomai_amd ``DecoderModel``s -- the
+algorithm, arguments, return values and order of random draws of the reference's ``speculative_generate``
+(VyomAI/speculative_decoding.py:86-245), which drives HF-style models with ``transformers`` caches.
 
-The reference drives HF-style models (``model(input_ids=, past_key_values=, use_cache=)`` with a
-``transformers`` cache); here drafter and target are the native decoders and the KV caches are
-``DynamicCacheOne`` objects that are trimmed in place after a rejection.  Every forward runs on the HIP
-path: with ``use_cache`` only the tokens a model has not seen go through the layers, and the vocabulary
-projection is evaluated only at the positions the algorithm reads (the last one for a draft, the
-gamma + 1 last ones for the verification).  Control flow, return values and the order of the random
-draws follow the reference line by line; ``rand_fn`` (default ``torch.rand`` on the target's device) only
-exists so that tests can fix the acceptance draws.
+Here drafter and target are the native decoders.  Each owns a ``DynamicCacheOne`` that is trimmed in place
+after a rejection; with ``use_cache`` only the tokens a model has not seen go through its layers, and the
+vocabulary projection is evaluated only where the algorithm reads it (the last position for a draft, the
+gamma + 1 last positions for the verification).  ``rand_fn`` (default ``torch.rand`` on the target's
+device) exists so that tests can fix the acceptance draws.
 """
 from __future__ import annotations
 
@@ -22,57 +20,63 @@ from .logits_processors import LogitsProcessor, NucleusProcessor
 
 
 def trim_cache(cache, num_tokens_to_discard: int):
-    """Drop the last ``num_tokens_to_discard`` tokens (reference :9-71).  Dynamic caches shrink in place;
-    static caches are written at ``start_pos`` on the next call, so their discarded slots are only
-    cleared."""
+    """Forget the last ``num_tokens_to_discard`` tokens of a cache (reference :9-71).  Dynamic caches shrink
+    in place (their buffers stay, the next write lands on the forgotten slots); static caches are written
+    at an explicit ``start_pos`` anyway and are returned as they are."""
     if cache is None:
         return None
-    n = int(num_tokens_to_discard)
-    if n <= 0:
-        return cache
+    drop = max(int(num_tokens_to_discard), 0)
     if isinstance(cache, DynamicCacheOne):
-        for b in cache._bufs:
-            b.length = max(b.length - n, 0)
+        bufs = cache._bufs
     elif isinstance(cache, DynamicCache):
-        cache._buf.length = max(cache._buf.length - n, 0)
+        bufs = [cache._buf]
     elif isinstance(cache, (StaticCacheOne, StaticCache)):
-        pass
+        bufs = []
     else:
         raise ValueError("Unsupported cache type.")
+    for buf in bufs:
+        buf.length = max(buf.length - drop, 0)
     return cache
 
 
 def norm_fn(x: Tensor) -> Tensor:
-    """norm(max(0, x)) (reference :73-83)."""
-    x_max = torch.where(x > 0, x, torch.zeros_like(x))
-    return x_max / torch.sum(x_max, dim=-1, keepdim=True)
+    """The positive part of x, normalised to sum 1 (reference :73-83)."""
+    pos = torch.where(x > 0, x, torch.zeros_like(x))   # (a NaN counts as 0, as in the reference)
+    return pos / pos.sum(dim=-1, keepdim=True)
 
 
-class _Stepper:
-    """A decoder and its cache: logits at positions [first, L) of a prefix of L tokens."""
+class _Decoder:
+    """One model of the pair with its cache: ``logits_from(tokens, first)`` -> (1, len - first, V) logits of the
+    positions first.. of the token prefix, running only what the cache does not hold yet."""
 
-    def __init__(self, model, use_cache: bool):
+    def __init__(self, model, cached: bool):
         self.model = model
-        self.cache = DynamicCacheOne(model.config) if use_cache else None
         self.device = next(model.parameters()).device
+        self.cache = DynamicCacheOne(model.config) if cached else None
 
-    def logits(self, ids: Tensor, first: int) -> Tensor:
-        ids = ids.to(self.device)
-        L = ids.shape[1]
-        mask = torch.ones((1, L), dtype=torch.long, device=self.device)
-        if self.cache is not None:
-            seen = len(self.cache)
-            if seen > first:
-                raise RuntimeError(f"cache holds {seen} tokens, logits wanted from position {first}")
-            hidden, self.cache = self.model.forward_hidden(ids[:, seen:], mask, True, self.cache, seen)
-            first -= seen
+    def logits_from(self, tokens: Tensor, first: int) -> Tensor:
+        tokens = tokens.to(self.device)
+        keys = torch.ones_like(tokens)
+        if self.cache is None:
+            hidden, _ = self.model.forward_hidden(tokens, keys)
         else:
-            hidden, _ = self.model.forward_hidden(ids, mask)
+            have = len(self.cache)
+            if have > first:
+                raise RuntimeError(f"the cache holds {have} tokens but logits are wanted from position {first}")
+            hidden, self.cache = self.model.forward_hidden(tokens[:, have:], keys, True, self.cache, have)
+            first -= have
         return self.model.lm_head(hidden[:, first:, :].contiguous())
 
-    def trim(self, n: int) -> None:
-        if self.cache is not None:
-            trim_cache(self.cache, n)
+    def forget(self, n: int) -> None:
+        trim_cache(self.cache, n)
+
+
+def _first_rejected(accept_ratio: Tensor, draws: Tensor) -> int:
+    """Index of the first draft whose draw exceeds p/q, or the number of drafts (reference :200-206)."""
+    for i in range(draws.shape[0]):
+        if draws[i] > accept_ratio[i]:
+            return i
+    return draws.shape[0]
 
 
 @torch.no_grad()
@@ -90,84 +94,67 @@ def speculative_generate(
     first_target: Optional[bool] = True,
     rand_fn: Optional[Callable[[int], Tensor]] = None,
 ) -> Tuple[List[int], float]:
-    """-> (generated ids, accepted drafts / speculated drafts).  Batch size 1 (reference :130)."""
-    if logits_processor is None:
-        logits_processor = NucleusProcessor(temperature=0.2, top_p=0.9)   # the reference's default (:91)
-    tgt, drf = _Stepper(target, bool(use_cache)), _Stepper(drafter, bool(use_cache))
-    dev = tgt.device
-    if rand_fn is None:
-        rand_fn = lambda n: torch.rand(n, device=dev)   # noqa: E731
-
-    list_tokens_id = eos_tokens_id if isinstance(eos_tokens_id, list) else [eos_tokens_id]
-    stop_tokens = torch.tensor(list_tokens_id, dtype=torch.long, device=dev).unsqueeze(1)
-    assert inputs.shape[0] == 1, "Speculative decoding only supports batch size 1."
-    assert drafter.config.vocab_size == target.config.vocab_size, \
-        "Drafter and target models should have the same vocabulary size."
-    drafts_accepted, drafts_speculated = .0, .0
-    vocabulary_size = target.config.vocab_size
-
-    prompt_len = len(inputs[0])
+    """-> (generated token ids, accepted drafts / proposed drafts).  One sequence at a time (reference :130)."""
+    proc = logits_processor if logits_processor is not None else NucleusProcessor(temperature=0.2, top_p=0.9)
+    if inputs.shape[0] != 1:
+        raise AssertionError("Speculative decoding only supports batch size 1.")
+    if drafter.config.vocab_size != target.config.vocab_size:
+        raise AssertionError("Drafter and target models should have the same vocabulary size.")
+    big, small = _Decoder(target, bool(use_cache)), _Decoder(drafter, bool(use_cache))
+    dev = big.device
+    draw = rand_fn if rand_fn is not None else (lambda n: torch.rand(n, device=dev))
+    stops = torch.tensor(eos_tokens_id if isinstance(eos_tokens_id, list) else [eos_tokens_id],
+                         dtype=torch.long, device=dev).unsqueeze(1)
     cfg = target.config
-    max_seq_length = cfg.max_position_embeddings if hasattr(cfg, "max_position_embeddings") else (
-        cfg.max_context_length if hasattr(cfg, "max_context_length") else 512)
-    total_len = min(max_seq_length, prompt_len + max_gen_len)
-    input_ids = torch.full((1, total_len), pad_token_id, dtype=torch.long, device=dev)
-    input_ids[0, :prompt_len] = inputs.to(dev)
-    current_position = prompt_len
+    limit = getattr(cfg, "max_position_embeddings", None) or getattr(cfg, "max_context_length", 512)
+    start = inputs.shape[1]
+    end = min(limit, start + max_gen_len)
+    seq = torch.full((1, end), pad_token_id, dtype=torch.long, device=dev)
+    seq[0, :start] = inputs.to(dev)[0]
+    pos = start
+    accepted = proposed = 0.0
 
-    if first_target:
-        # prefill the target's cache and take a first token from it (reference :148-162)
-        p_p = logits_processor(tgt.logits(input_ids[..., :current_position], current_position - 1)[..., -1, :])
-        t = logits_processor.sample(p_p)
-        input_ids[0, current_position] = t
-        current_position += 1
-        if torch.isin(t, stop_tokens):
-            return input_ids[0, prompt_len:current_position].tolist(), 0
+    def finished(upto: int):
+        return seq[0, start:upto].tolist(), (accepted / proposed if proposed else 0)
 
-    while current_position < total_len:
-        corrected_gamma = min(gamma, total_len - current_position - 1)
-        q = torch.zeros((1, corrected_gamma, vocabulary_size), device=dev)
+    if first_target:   # the target prefills its cache and contributes the first token (reference :148-162)
+        tok = proc.sample(proc(big.logits_from(seq[:, :pos], pos - 1)[:, -1, :]))
+        seq[0, pos] = tok
+        pos += 1
+        if torch.isin(tok, stops):
+            return seq[0, start:pos].tolist(), 0
 
-        for k in range(corrected_gamma):   # gamma drafts (reference :172-185)
-            draft_logits = drf.logits(input_ids[..., :current_position + k], current_position + k - 1)[..., -1, :]
-            draft_probs = logits_processor(draft_logits)
-            q[0, k] = draft_probs.to(dev)
-            xi = logits_processor.sample(draft_probs)
-            input_ids[0, current_position + k] = xi
-        drafts_speculated += corrected_gamma
+    while pos < end:
+        g = min(gamma, end - pos - 1)
+        q = torch.zeros((1, g, cfg.vocab_size), device=dev)
+        for j in range(g):   # the drafter proposes g tokens (reference :172-185)
+            q[0, j] = proc(small.logits_from(seq[:, :pos + j], pos + j - 1)[:, -1, :]).to(dev)
+            seq[0, pos + j] = proc.sample(q[:, j])
+        proposed += g
 
-        # the target on the drafts: logits of positions current-1 .. current+gamma-1 (reference :189-197)
-        mp = tgt.logits(input_ids[..., :current_position + corrected_gamma], current_position - 1)
-        p = logits_processor(mp[..., :corrected_gamma, :])
+        # one target pass scores them all: logits of positions pos-1 .. pos+g-1 (reference :189-197)
+        scores = big.logits_from(seq[:, :pos + g], pos - 1)
+        p = proc(scores[:, :g, :])
+        ratio = (p / q)[0, torch.arange(g, device=dev), seq[0, pos:pos + g]]
+        n = _first_rejected(ratio, draw(g))
+        accepted += n
 
-        r = rand_fn(corrected_gamma)
-        fractions = p / q
-        n = corrected_gamma
-        for i in range(corrected_gamma):   # rejection sampling (reference :200-206)
-            if r[i] > fractions[0, i, input_ids[0, current_position + i]]:
-                n = i
-                break
-        drafts_accepted += n
+        hit = torch.nonzero(torch.eq(seq[:, pos:pos + n], stops))   # a stop token among the accepted (:211-216)
+        if hit.shape[0] > 0:
+            return finished(pos + int(hit[0, 1]) + 1)
 
-        stop_locations = torch.nonzero(torch.eq(input_ids[..., current_position:current_position + n], stop_tokens))
-        if stop_locations.shape[0] > 0:
-            stop_location = stop_locations[0, 1].item()
-            return (input_ids[0, prompt_len:current_position + stop_location + 1].tolist(),
-                    drafts_accepted / drafts_speculated)
-
-        if n == corrected_gamma:
-            p_p = logits_processor(mp[..., corrected_gamma, :])
+        if n == g:
+            nxt = proc.sample(proc(scores[:, g, :]))
         else:
-            if use_cache:
-                drf.trim(corrected_gamma - n)
-                tgt.trim(corrected_gamma - n + 1)
-            p_p = p[..., n, :] if skip_sample_adjustment else norm_fn(p[..., n, :] - q[0, n, :])
-        x = logits_processor.sample(p_p)
+            if use_cache:   # both caches go back to the last accepted token (reference :224-226)
+                small.forget(g - n)
+                big.forget(g - n + 1)
+            resid = p[:, n, :] if skip_sample_adjustment else norm_fn(p[:, n, :] - q[0, n, :])
+            nxt = proc.sample(resid)
+        seq[0, pos + n:pos + g] = pad_token_id
+        seq[0, pos + n] = nxt
+        pos += n + 1
+        if torch.isin(nxt, stops):
+            return finished(pos)
 
-        input_ids[0, current_position + n:current_position + corrected_gamma] = pad_token_id
-        input_ids[0, current_position + n] = x
-        current_position += n + 1
-        if torch.isin(x, stop_tokens):
-            return input_ids[0, prompt_len:current_position].tolist(), drafts_accepted / drafts_speculated
-
-    return input_ids[0, prompt_len:].tolist(), drafts_accepted / drafts_speculated
+    return finished(end)
