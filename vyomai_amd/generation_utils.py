@@ -7,12 +7,15 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from . import ops
+
 
 def _pick(logits: torch.Tensor, temperature: float, do_sample: bool) -> torch.Tensor:
-    probs = torch.softmax(logits.float() / temperature, dim=-1)
+    """softmax(logits / temperature) (vy_sampling_probs), then a draw or the most probable token."""
+    probs = ops.sampling_probs(logits, temperature)
     if do_sample:
         return torch.multinomial(probs, num_samples=1)
-    return torch.topk(probs, k=1, dim=-1)[1]
+    return probs.argmax(dim=-1, keepdim=True)
 
 
 @torch.no_grad()
