@@ -164,6 +164,20 @@ int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, fl
                     int64_t lddw, float* db, float beta, const float* alpha_dev, int64_t M, int64_t N,
                     int64_t K, int dtype, void* stream);
 
+/* Several weight gradients in one launch: dW_i += dY_i^T X_i and db_i += column sums of dY_i (db_i may be NULL)
+ * for 1..8 GEMMs, accumulating (the beta = 1 form of vy_linear_wgrad).  The four projections of a
+ * transformer layer (reference: the autograd of the nn.Linear layers at layers/attention.py:87-95, :57-72,
+ * layers/ffn.py:19-40) are small as wgrad problems -- 9 to 36 output tiles of 256 x 256 -- and filling the
+ * chip one at a time costs M-splits, i.e. fp32 atomic traffic; together they need a quarter of it. */
+typedef struct vy_wgrad_desc {
+  const void* dy; int64_t lddy;
+  const void* x; int64_t ldx;
+  float* dw; int64_t lddw;
+  float* db;
+  int64_t M, N, K;
+} vy_wgrad_desc;
+int vy_linear_wgrad_grouped(const vy_wgrad_desc* descs, int32_t n, int dtype, void* stream);
+
 /* LayerNorm backward: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma;
  * dgamma/dbeta fp32 [N] accumulated (beta) from per-block partials in `ws`
  * (ws: fp32, at least 2 * ws_rows * N elements; ws_rows = vy_layernorm_bwd_ws_rows(M)). */

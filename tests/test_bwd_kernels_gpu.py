@@ -32,6 +32,33 @@ def test_wgrad(M, N, K):
     check(dw, 2 * want, 2 * tol, 1e-3, "dW accumulate")
 
 
+def test_wgrad_grouped():
+    """vy_linear_wgrad_grouped: several accumulating weight gradients in one launch (256 x 256 tiles), ragged
+    N / K / M, with and without a bias gradient, rows of the operands strided."""
+    ops = _ops()
+    shapes = [(4096, 768, 768, True), (4096, 3072, 768, True), (4096, 768, 3072, False), (4100, 2304, 768, True),
+              (1000, 520, 264, True), (300, 56, 8, False)]
+    items, wants = [], []
+    for i, (M, N, K, bias) in enumerate(shapes):
+        dy_full = rnd(M, N + 8, seed=10 + i).to(BF).to(DEV)       # row stride N + 8
+        dy, x = dy_full[:, :N], rnd(M, K, seed=30 + i).to(BF).to(DEV)
+        dw = torch.full((N, K), 3.0, dtype=torch.float32, device=DEV)
+        db = torch.full((N,), 3.0, dtype=torch.float32, device=DEV) if bias else None
+        items.append((dy, x, dw, db))
+        wants.append((dy.double().t() @ x.double(), dy.double().sum(0), M))
+    ops.linear_wgrad_grouped(items)
+    for (dy, x, dw, db), (w_dw, w_db, M) in zip(items, wants):
+        tol = 2e-3 * math.sqrt(M)
+        check(dw, w_dw.cpu() + 3.0, tol, 1e-3, "grouped dW (accumulated onto 3.0)")
+        if db is not None:
+            check(db, w_db.cpu() + 3.0, tol, 1e-3, "grouped db")
+    ops.linear_wgrad_grouped(items[:1])      # a group of one
+    check(items[0][2], 2 * wants[0][0].cpu() + 3.0, 4e-3 * math.sqrt(4096), 1e-3, "second accumulation")
+    from vyomai_amd._lib import VyomHipError
+    with pytest.raises(VyomHipError):
+        ops.linear_wgrad_grouped([(items[0][0][:, :767], items[0][1][:, :767], items[0][2][:767, :767], None)])   # K % 8
+
+
 @pytest.mark.parametrize("M,N,K,act", [(300, 768, 3072, 1), (1024, 768, 768, 0), (51, 3072, 768, 0)])
 def test_dgrad(M, N, K, act):
     """dX[M,K] = dY[M,N] @ W[N,K] (* gelu'(pre)) (+ add)."""

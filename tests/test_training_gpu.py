@@ -231,3 +231,42 @@ def test_unfused_lm_head_backward_matches_fused_loss():
     assert abs(grads[0][0] - grads[1][0]) < 2e-2
     err = (grads[0][1] - grads[1][1]).abs().max() / grads[0][1].abs().max()
     assert err < 3e-2, err
+
+
+def test_grouped_weight_gradients_match_ungrouped():
+    """At training sizes (>= 4096 rows) the weight gradients of a layer are deferred and launched together
+    (autograd_train._WgradGroup): same gradients as one launch per projection, every parameter reported ready
+    exactly once, nothing left pending after backward."""
+    import vyomai_amd as V
+    from vyomai_amd import autograd_train as AT
+    from vyomai_amd.training import FlatTrainer
+    cfg = cases.with_kv(cases.test_cfg(), None)
+    cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size = 2, 512, 8, 2048
+    cfg.hidden_dropout_prob, cfg.vocab_size = 0.0, 1000
+    ids = T(recipe.token_ids("grp.ids", (8, 512), 3, cfg.vocab_size)).to(DEV)
+    grads = {}
+    for grouped in (False, True):
+        m = V.DecoderModel(cfg, "rope", None)
+        recipe.load_recipe_(m)
+        m = m.to(DEV).train()
+        tr = FlatTrainer(m, lr=1e-3)
+        old = AT._GROUP_WGRADS
+        AT._GROUP_WGRADS = grouped
+        launches = []
+        real = AT.ops.linear_wgrad_grouped
+        AT.ops.linear_wgrad_grouped = lambda items: (launches.append(len(items)), real(items))[1]
+        try:
+            tr.zero_grad()
+            loss = m.clm_loss(ids, ids)
+            tr.backward(loss)
+        finally:
+            AT._GROUP_WGRADS = old
+            AT.ops.linear_wgrad_grouped = real
+        assert not AT._wgrad_group.items and not AT._wgrad_group.armed
+        assert (len(launches) > 0) == grouped, launches
+        torch.cuda.synchronize()
+        grads[grouped] = tr.arena.grad.clone()
+    a, b = grads[False], grads[True]
+    assert torch.isfinite(b).all()
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= 2e-3 * scale, ((a - b).abs().max().item(), scale)

@@ -36,6 +36,7 @@ PROTOTYPES = {
     "vy_rope_fwd": [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i, _i64, _i, _i, _i, _p],
     "vy_linear_dgrad": [_p, _i64, _p, _i64, _p, _i64, _i, _p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i64, _i, _p],
     "vy_linear_wgrad": [_p, _i64, _p, _i64, _p, _i64, _p, _f, _p, _i64, _i64, _i64, _i, _p],
+    "vy_linear_wgrad_grouped": [_p, _i, _i, _p],
     "vy_layernorm_bwd": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _p, _f, _p, _i64, _i64, _i, _p],
     "vy_attn_bwd": [_p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,
                     _p, _p, _i64, _i64, _p, _p,
@@ -57,6 +58,12 @@ PROTOTYPES = {
 }
 OTHER_SYMBOLS = ["vy_last_error", "vy_abi_version", "vy_layernorm_bwd_ws_rows", "vy_decode_ws_bytes"]
 ALL_SYMBOLS = list(PROTOTYPES) + OTHER_SYMBOLS
+
+
+class VyWgradDesc(C.Structure):
+    """vy_wgrad_desc of include/vyom_hip.h."""
+    _fields_ = [("dy", _p), ("lddy", _i64), ("x", _p), ("ldx", _i64), ("dw", _p), ("lddw", _i64), ("db", _p),
+                ("M", _i64), ("N", _i64), ("K", _i64)]
 
 
 class VyomHipError(RuntimeError):

@@ -12,6 +12,8 @@ Gradient delivery has two modes per parameter:
 """
 from __future__ import annotations
 
+import os
+
 import weakref
 from typing import Optional
 
@@ -111,9 +113,60 @@ def _notify(*params) -> None:
                 cb(p)
 
 
+class _WgradGroup:
+    """Weight gradients that accumulate straight into the gradient arena do not have to be launched where
+    autograd reaches them: the projections of a layer are small wgrad problems (9-36 tiles of 256 x 256),
+    and one at a time each needs M-splits -- fp32 atomic traffic -- to fill the chip.  They are collected
+    here and go out as ONE launch per ~layer (vy_linear_wgrad_grouped); the parameters are reported ready
+    (DDP buckets, per-bucket AdamW) when that launch has been enqueued.  Whatever is still pending when
+    the backward pass ends is flushed by an autograd-engine callback."""
+
+    TILES = int(os.environ.get("VY_WGRAD_GROUP_TILES", "100"))   # flush once this many 256 x 256 output tiles are pending (one post-LN layer: 108)
+
+    def __init__(self):
+        self.items, self.tiles, self.armed = [], 0, False
+
+    def wants(self, dy, w, alpha) -> bool:
+        if alpha is not None or not _GROUP_WGRADS:
+            return False
+        N, K = w.shape
+        return dy.numel() // N >= 4096 and N < 8192 and N * K >= 512 * 512 and K % 8 == 0
+
+    def add(self, dy, x, w, b) -> None:
+        self.items.append((dy, x, w, b))
+        self.tiles += -(-w.shape[0] // 256) * -(-w.shape[1] // 256)
+        if not self.armed:
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            self.armed = True
+        if self.tiles >= self.TILES or len(self.items) == 8:
+            self.flush()
+
+    def flush(self) -> None:
+        items, self.items, self.tiles = self.items, [], 0
+        if not items:
+            return
+        ops.linear_wgrad_grouped([(dy, x, w.grad, None if b is None else b.grad) for dy, x, w, b in items])
+        for _, _, w, b in items:
+            _notify(w, b)
+
+    def _end_of_backward(self) -> None:
+        self.armed = False
+        self.flush()
+
+    def discard(self) -> None:
+        self.items, self.tiles, self.armed = [], 0, False
+
+
+_GROUP_WGRADS = os.environ.get("VY_WGRAD_GROUP", "1") != "0"
+_wgrad_group = _WgradGroup()
+
+
 def _wgrad(dy, x, w: torch.Tensor, b: Optional[torch.Tensor], alpha: Optional[torch.Tensor] = None):
     """-> (dw, db) to return to autograd (None when accumulated in place)."""
     if _direct(w) and (b is None or _direct(b)):
+        if _wgrad_group.wants(dy, w, alpha):
+            _wgrad_group.add(dy, x, w, b)
+            return None, None
         ops.linear_wgrad(dy, x, w.grad, None if b is None else b.grad, accumulate=True, alpha=alpha)
         _notify(w, b)
         return None, None

@@ -50,10 +50,10 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
 // 80 KiB at 128 x 128 x 64: still two workgroups per CU) -- the dY loads of stage s+2 stay in flight
 // across the barrier that ends stage s, as X does in gemm_nt_bf16_x3_kernel.
 template <int BN, int BKW, int MS, int NS>
-__global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kernel(
+__device__ __forceinline__ void wgrad_tn_bf16_body(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
     float* __restrict__ dW, int64_t lddw, float* __restrict__ db, const float* __restrict__ alpha_dev,
-    int M, int N, int K, int tiles_k, int tiles_nk, int m_chunk, int diag) {
+    int M, int N, int K, int tiles_k, int tiles_nk, int m_chunk, int diag, int wg) {
   constexpr int NW = BN / 32;                 // waves: (BN/64) x 2
   constexpr int WKT = BKW / 2, TJ = WKT / 32; // k extent of a wave, 32-wide fragments along k
   constexpr int AROW = BN * 2, BROW = BKW * 2;  // LDS row bytes of the dY and X tiles
@@ -67,7 +67,6 @@ __global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kerne
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int split = wg / tiles_nk, t2 = wg - split * tiles_nk;
   const int tile_n = t2 / tiles_k, tile_k = t2 - tile_n * tiles_k;
   const int n0 = tile_n * BN, k0 = tile_k * BKW;
@@ -273,6 +272,41 @@ __global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kerne
         if (n < N) atomicAdd(dW + (int64_t)n * lddw + k, acc[i][j][r] * alpha);
       }
     }
+}
+
+template <int BN, int BKW, int MS, int NS>
+__global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kernel(
+    const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
+    float* __restrict__ dW, int64_t lddw, float* __restrict__ db, const float* __restrict__ alpha_dev,
+    int M, int N, int K, int tiles_k, int tiles_nk, int m_chunk, int diag) {
+  wgrad_tn_bf16_body<BN, BKW, MS, NS>(dY, lddy, X, ldx, dW, lddw, db, alpha_dev, M, N, K, tiles_k, tiles_nk, m_chunk,
+                                      diag, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Several weight gradients in ONE launch (vy_linear_wgrad_grouped): the four GEMMs of a transformer layer
+// have 9-36 tiles of 256 x 256 each -- alone, a launch needs 7 M-splits to fill 256 CUs (66 MB of fp32
+// atomics); together they are 108 tiles and need 2.  The table travels in the kernel arguments.
+struct WgradItem {
+  const bf16* dY; const bf16* X; float* dW; float* db;
+  int64_t lddy, ldx, lddw;
+  int M, N, K, tiles_k, tiles_nk, m_chunk, item0;   // item0: first work item of this GEMM
+};
+struct WgradGroup { WgradItem g[8]; int n; };
+
+template <int BN, int BKW, int MS, int NS>
+__global__ __launch_bounds__(BN * 2, 1) void wgrad_tn_bf16_grouped_kernel(WgradGroup grp, int diag) {
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  int d = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < grp.n && id >= grp.g[i].item0) d = i;
+  // (selected with a uniform loop: the descriptor lives in SGPRs after this)
+  WgradItem it = grp.g[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (d == i) it = grp.g[i];
+  wgrad_tn_bf16_body<BN, BKW, MS, NS>(it.dY, it.lddy, it.X, it.ldx, it.dW, it.lddw, it.db, nullptr, it.M, it.N, it.K,
+                                      it.tiles_k, it.tiles_nk, it.m_chunk, diag, id - it.item0);
 }
 
 // db[n] += sum_m dY[m,n]: block = 64 lanes x 8 columns, 256 rows per block
@@ -846,6 +880,45 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   else if (var == 8) WG_GO(256, 256, 32, 4);   // ... 128 KiB
   else { if (ns == 3) WG_GO(128, 128, 64, 3); else WG_GO(128, 128, 64, 2); }
 #undef WG_GO
+  VY_CHECK_LAUNCH(who);
+  return VY_OK;
+}
+
+extern "C" int vy_linear_wgrad_grouped(const vy_wgrad_desc* descs, int32_t n, int dtype, void* stream) {
+  const char* who = "vy_linear_wgrad_grouped";
+  if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only", who);
+  if (!descs || n <= 0 || n > 8) VY_FAIL(VY_ERR_ARG, "%s: 1..8 descriptors", who);
+  int64_t tiles_total = 0;
+  for (int i = 0; i < n; ++i) {
+    const vy_wgrad_desc& d = descs[i];
+    if (!d.dy || !d.x || !d.dw || d.M <= 0 || d.N <= 0 || d.K <= 0) VY_FAIL(VY_ERR_ARG, "%s: descriptor %d: bad arguments", who, i);
+    if (d.K % 8 || d.lddy % 8 || d.ldx % 8 || d.lddy < vy_cdiv(d.N, 8) * 8 || (uintptr_t)d.dy % 16 || (uintptr_t)d.x % 16)
+      VY_FAIL(VY_ERR_ARG, "%s: descriptor %d: K and leading dimensions must be multiples of 8, operands 16-byte aligned", who, i);
+    tiles_total += vy_cdiv(d.N, 256) * vy_cdiv(d.K, 256);
+  }
+  static const int tgt = [] { const char* e = getenv("VY_WGRAD_GROUP_TARGET"); return e ? atoi(e) : 256; }();
+  static const int diag = [] { const char* e = getenv("VY_WGRAD_DIAG"); return e ? atoi(e) : 0; }();
+  const int64_t want = tgt / tiles_total > 0 ? tgt / tiles_total : 1;   // M-splits: at most one round of workgroups
+  WgradGroup grp;
+  grp.n = n;
+  int64_t items = 0;
+  for (int i = 0; i < n; ++i) {
+    const vy_wgrad_desc& d = descs[i];
+    const int64_t tiles_k = vy_cdiv(d.K, 256), tiles = vy_cdiv(d.N, 256) * tiles_k;
+    int64_t splits = want, max_splits = vy_cdiv(d.M, 256);
+    if (splits > max_splits) splits = max_splits;
+    const int64_t m_chunk = vy_cdiv(vy_cdiv(d.M, splits), 64) * 64;
+    splits = vy_cdiv(d.M, m_chunk);
+    WgradItem& it = grp.g[i];
+    it.dY = (const bf16*)d.dy; it.X = (const bf16*)d.x; it.dW = d.dw; it.db = d.db;
+    it.lddy = d.lddy; it.ldx = d.ldx; it.lddw = d.lddw;
+    it.M = (int)d.M; it.N = (int)d.N; it.K = (int)d.K;
+    it.tiles_k = (int)tiles_k; it.tiles_nk = (int)tiles; it.m_chunk = (int)m_chunk; it.item0 = (int)items;
+    items += tiles * splits;
+  }
+  for (int i = n; i < 8; ++i) grp.g[i] = grp.g[0];
+  hipLaunchKernelGGL((wgrad_tn_bf16_grouped_kernel<256, 256, 32, 4>), dim3((unsigned)items), dim3(512), 0, (hipStream_t)stream,
+                     grp, diag);
   VY_CHECK_LAUNCH(who);
   return VY_OK;
 }

@@ -219,6 +219,31 @@ def linear_wgrad(dy: Tensor, x: Tensor, dw: Tensor, db: Optional[Tensor], accumu
          dw.stride(0), _ptr(db), 1.0 if accumulate else 0.0, _ptr(alpha), M, N, K, dtype_code(dy.dtype), _stream())
 
 
+def linear_wgrad_grouped(items) -> None:
+    """items: up to 8 tuples (dy, x, dw, db|None): dw += dy^T @ x, db += colsum(dy), ONE launch
+    (vy_linear_wgrad_grouped).  The tensors must stay alive until the launch has been enqueued (they do:
+    the caller holds them)."""
+    import ctypes as C
+    n = len(items)
+    assert 1 <= n <= 8
+    arr = (_lib.VyWgradDesc * n)()
+    dt = None
+    for i, (dy, x, dw, db) in enumerate(items):
+        _need_gpu(dy, x, dw, db)
+        d2, x2 = _rows(dy), _rows(x)
+        M, N = d2.shape
+        K = x2.shape[1]
+        assert x2.shape[0] == M and dw.dtype == torch.float32 and dw.shape == (N, K) and dw.stride(1) == 1
+        assert db is None or (db.dtype == torch.float32 and db.numel() == N)
+        assert dt is None or dt == dy.dtype
+        dt = dy.dtype
+        a = arr[i]
+        a.dy, a.lddy, a.x, a.ldx = d2.data_ptr(), d2.stride(0), x2.data_ptr(), x2.stride(0)
+        a.dw, a.lddw, a.db = dw.data_ptr(), dw.stride(0), _ptr(db)
+        a.M, a.N, a.K = M, N, K
+    call("vy_linear_wgrad_grouped", C.cast(arr, C.c_void_p), n, dtype_code(dt), _stream())
+
+
 def layernorm_bwd(dy: Tensor, x: Tensor, gamma: Tensor, mean: Tensor, rstd: Tensor, dgamma: Tensor,
                   dbeta: Tensor, accumulate: bool) -> Tensor:
     _need_gpu(dy, x, gamma, mean, rstd, dgamma, dbeta)

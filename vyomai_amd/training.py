@@ -250,6 +250,8 @@ class FlatTrainer:
             self.reducer.on_bucket = self._bucket_final
 
     def zero_grad(self) -> None:
+        from .autograd_train import _wgrad_group
+        _wgrad_group.discard()   # (only an aborted backward can have left deferred weight gradients behind)
         self.arena.zero_grad()
         self.reducer.reset()
         self._stepped = set()
