@@ -1,5 +1,8 @@
+"""wgrad of a stacked problem with as many 256 x 256 tiles as one / two layers have together (N = 9216 / 18432):
+VY_WGRAD_VARIANT=8 VY_WGRAD_TARGET=216 python tools/bench_wgrad_stacked.py  vs  VY_WGRAD_VARIANT=0 -- the estimate
+behind vy_linear_wgrad_grouped."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vyomai_amd import ops
 from tools.bench_kernels import timeit
 M = 16384
