@@ -235,38 +235,56 @@ def test_unfused_lm_head_backward_matches_fused_loss():
 
 def test_grouped_weight_gradients_match_ungrouped():
     """At training sizes (>= 4096 rows) the weight gradients of a layer are deferred and launched together
-    (autograd_train._WgradGroup): same gradients as one launch per projection, every parameter reported ready
-    exactly once, nothing left pending after backward."""
+    (autograd_train._WgradGroup): same gradients and the same training trajectory as one launch per projection;
+    no parameter is reported ready (DDP bucket / per-bucket AdamW) while its gradient launch is still pending --
+    autograd's own post-accumulate hook fires earlier than that and must be ignored for deferred weights."""
     import vyomai_amd as V
     from vyomai_amd import autograd_train as AT
     from vyomai_amd.training import FlatTrainer
     cfg = cases.with_kv(cases.test_cfg(), None)
-    cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size = 2, 512, 8, 2048
+    cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size = 3, 512, 8, 2048
     cfg.hidden_dropout_prob, cfg.vocab_size = 0.0, 1000
     ids = T(recipe.token_ids("grp.ids", (8, 512), 3, cfg.vocab_size)).to(DEV)
-    grads = {}
+    grads, losses, finals = {}, {}, {}
     for grouped in (False, True):
         m = V.DecoderModel(cfg, "rope", None)
         recipe.load_recipe_(m)
         m = m.to(DEV).train()
-        tr = FlatTrainer(m, lr=1e-3)
+        tr = FlatTrainer(m, lr=1e-3, bucket_bytes=4 << 20)     # several buckets: some are final mid-backward
+        early, launches = [], []
+        real_ready = tr.reducer.mark_ready
+
+        def spy(p):
+            if any(p is w or p is b for _, _, w, b in AT._wgrad_group.items):
+                early.append(p)
+            real_ready(p)
+
+        tr.reducer.mark_ready = spy
+        for p in tr.arena.params:
+            p._vy_ready = spy
         old = AT._GROUP_WGRADS
         AT._GROUP_WGRADS = grouped
-        launches = []
         real = AT.ops.linear_wgrad_grouped
         AT.ops.linear_wgrad_grouped = lambda items: (launches.append(len(items)), real(items))[1]
         try:
             tr.zero_grad()
             loss = m.clm_loss(ids, ids)
             tr.backward(loss)
+            assert not AT._wgrad_group.items and not AT._wgrad_group.armed
+            torch.cuda.synchronize()
+            grads[grouped] = tr.arena.grad.clone()
+            losses[grouped] = [float(tr.train_step(lambda: m.clm_loss(ids, ids))) for _ in range(4)]
+            torch.cuda.synchronize()
+            finals[grouped] = tr.arena.master.clone()
         finally:
             AT._GROUP_WGRADS = old
             AT.ops.linear_wgrad_grouped = real
-        assert not AT._wgrad_group.items and not AT._wgrad_group.armed
         assert (len(launches) > 0) == grouped, launches
-        torch.cuda.synchronize()
-        grads[grouped] = tr.arena.grad.clone()
+        assert not early, f"{len(early)} parameters were reported ready before their gradient launch"
     a, b = grads[False], grads[True]
     assert torch.isfinite(b).all()
     scale = a.abs().max().item()
     assert (a - b).abs().max().item() <= 2e-3 * scale, ((a - b).abs().max().item(), scale)
+    assert losses[True][-1] < losses[True][0]
+    assert max(abs(x - y) for x, y in zip(losses[False], losses[True])) < 2e-2, (losses[False], losses[True])
+    assert (finals[False] - finals[True]).abs().max().item() < 5e-3

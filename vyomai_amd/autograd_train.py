@@ -134,6 +134,11 @@ class _WgradGroup:
 
     def add(self, dy, x, w, b) -> None:
         self.items.append((dy, x, w, b))
+        # autograd's own post-accumulate hook fires for these parameters as soon as this backward function
+        # returns -- the reducer must not take that for "gradient written" (training.BucketReducer._hook)
+        w._vy_deferred = True
+        if b is not None:
+            b._vy_deferred = True
         self.tiles += -(-w.shape[0] // 256) * -(-w.shape[1] // 256)
         if not self.armed:
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
@@ -147,6 +152,9 @@ class _WgradGroup:
             return
         ops.linear_wgrad_grouped([(dy, x, w.grad, None if b is None else b.grad) for dy, x, w, b in items])
         for _, _, w, b in items:
+            w._vy_deferred = False
+            if b is not None:
+                b._vy_deferred = False
             _notify(w, b)
 
     def _end_of_backward(self) -> None:
@@ -154,6 +162,10 @@ class _WgradGroup:
         self.flush()
 
     def discard(self) -> None:
+        for _, _, w, b in self.items:
+            w._vy_deferred = False
+            if b is not None:
+                b._vy_deferred = False
         self.items, self.tiles, self.armed = [], 0, False
 
 

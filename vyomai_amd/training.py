@@ -175,7 +175,10 @@ class BucketReducer:
             p.register_post_accumulate_grad_hook(self._hook)
 
     def _hook(self, p) -> None:
-        self.mark_ready(p)
+        # (a weight whose gradient launch has been deferred -- autograd_train._WgradGroup -- reports itself
+        # when that launch has been enqueued; the tape's hook comes too early for it)
+        if not getattr(p, "_vy_deferred", False):
+            self.mark_ready(p)
 
     def reset(self) -> None:
         self._pending = [0] * len(self.buckets)
