@@ -86,7 +86,7 @@ __global__ __launch_bounds__(ST) void greedy_step_kernel(const T* __restrict__ l
       int i = bi[0];
       for (int w = 1; w < SW; ++w)
         if (bi[w] != 0x7fffffff && (i == 0x7fffffff || bv[w] > v || (bv[w] == v && bi[w] < i))) { v = bv[w]; i = bi[w]; }
-      next = i;
+      next = i == 0x7fffffff ? 0 : i;   // a row of NaNs has no maximum: token 0, not an out-of-range id
       tokens[(int64_t)b * ldt + cur_pos] = next;
     }
     bool eos = eos_reached[b];
