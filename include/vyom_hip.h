@@ -315,6 +315,37 @@ int64_t vy_decode_ws_bytes(int32_t B, int32_t d, int32_t h, int32_t hk, int32_t 
 int vy_decoder_step(const vy_decode_plan* plan, const void* x, int64_t pos, const int32_t* pos_dev,
                     void* hidden_out, void* logits, int64_t ldv, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * vy_gemma_decoder_step: one single-token step of a Gemma-style decoder stack (BASELINE configs[4], the
+ * PaliGemma-shape language model; Examples/paligemma.ipynb cells 11-13): per layer
+ *   n = RMSNorm(x) ; q,k,v = n Wqkv^T (+b) with RoPE, k/v written into the cache at `pos` ;
+ *   x = x + attn(q, K[0..pos], V[0..pos]) Wo^T ; n = RMSNorm(x) ; x = x + (gelu_tanh(n Wg^T) * n Wu^T) Wd^T
+ * then the final RMSNorm and the (tied) vocabulary projection.  Same launches as the Python layer
+ * (models/paligemma.py GemmaDecoderLayer), one C call per generated token instead of ~150.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct vy_gemma_layer {
+  const void* wqkv; const void* bqkv;      /* packed [q;k;v] projection, bias may be NULL */
+  const void* wo; const void* bo;
+  const void* ln_in; const void* ln_post;  /* RMSNorm weights (applied as 1 + w) */
+  const void* wgu;                         /* packed [gate; up], [2*ffn, d] */
+  const void* wdown;                       /* [d, ffn] */
+  void* kcache; void* vcache;              /* (B, hk, cap, dh) */
+  int64_t c_sb, c_sh, c_sl;
+} vy_gemma_layer;
+typedef struct vy_gemma_plan {
+  int32_t num_layers, B, d, h, hk, dh, ffn, vocab, dtype;
+  float eps;
+  const float* cos_tab; const float* sin_tab;
+  const vy_gemma_layer* layers;
+  const void* norm_w; const void* head_w;  /* final RMSNorm, [vocab, d] projection */
+  void* ws; int64_t ws_bytes;              /* >= vy_gemma_ws_bytes(...) */
+} vy_gemma_plan;
+int64_t vy_gemma_ws_bytes(int32_t B, int32_t d, int32_t h, int32_t dh, int32_t ffn, int32_t dtype);
+/* x: (B, d) embeddings of the current token (already scaled by sqrt(d)); keys 0..pos are attended;
+ * logits: (B, ldv). */
+int vy_gemma_decoder_step(const vy_gemma_plan* plan, const void* x, int64_t pos, void* logits, int64_t ldv,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

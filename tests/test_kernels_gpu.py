@@ -48,6 +48,8 @@ ACTS = {0: lambda x: x, 1: O.gelu_erf, 2: O.gelu_tanh}
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (51, 1003, 768), (300, 768, 72),
                                    (16, 768, 768), (1, 256, 3072), (1024, 3072, 768), (640, 768, 3072),
                                    (32, 3072, 768), (32, 1003, 768), (7, 768, 3072), (32, 64, 40),
+                                   # <= 4 rows: the matrix-vector kernel (one wave per output column)
+                                   (1, 2048, 16384), (2, 1003, 768), (3, 770, 264), (4, 768, 3072), (1, 5, 8),
                                    # > 1024 rows: the 256 x 192 tile kernel (M / N / K tails)
                                    (2000, 768, 768), (4096, 1003, 768), (1500, 384, 72), (3072, 3072, 768)])
 @pytest.mark.parametrize("act", [0, 1])

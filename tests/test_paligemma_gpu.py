@@ -118,3 +118,37 @@ def test_paligemma_shape_generate_bf16_runs():
     ids = T(recipe.token_ids("pgm.ids", (1, 8), 3, 4096)).to(DEV)
     out = m.generate(img, ids, max_new_tokens=6, max_cache_len=384)
     assert out.shape == (1, 6) and int(out.min()) >= 0 and int(out.max()) < 4096
+
+
+def test_native_gemma_step_matches_the_layer_by_layer_loop():
+    """generate() drives the language model with one vy_gemma_decoder_step call per token; the same tokens and the
+    same last-step logits must come out of the Python loop over GemmaDecoderLayer.forward (bf16, M = 1: both use the
+    same kernels in the same order)."""
+    from vyomai_amd.models import paligemma as P
+    from vyomai_amd import ops
+    vis = P.SiglipVisionConfig(**dict(cases.SIGLIP, num_hidden_layers=1))
+    txt = types.SimpleNamespace(**dict(cases.GEMMA, num_hidden_layers=3, vocab_size=5000, intermediate_size=2048))
+    m = P.PaliGemmaForConditionalGeneration(P.PaliGemmaShape(vis, txt, txt.hidden_size))
+    for n, p in m.named_parameters():
+        with torch.no_grad():
+            p.copy_(T(recipe.param_value("pgn." + n, tuple(p.shape))))
+    m = m.to(DEV).to(torch.bfloat16).eval()
+    img = T(recipe.uniform("pgn.img", (2, 3, 224, 224), 0.5, 0.5)).to(DEV)
+    ids = T(recipe.token_ids("pgn.ids", (2, 5), 3, 5000)).to(DEV)
+    steps = 7
+    got = m.generate(img, ids, max_new_tokens=steps, max_cache_len=300)
+    # the loop the notebook runs (cell 30), layer by layer through the Python modules
+    with torch.no_grad():
+        dt = torch.bfloat16
+        emb = ops.linear(m.vision_tower(img.to(dt)), m.multi_modal_projector.weight, m.multi_modal_projector.bias)
+        hidden = torch.cat([emb, m.embed_tokens(ids)], dim=1)
+        caches = [(torch.zeros(2, 1, 300, 256, dtype=dt, device=DEV), torch.zeros(2, 1, 300, 256, dtype=dt, device=DEV))
+                  for _ in m.layers]
+        pos = hidden.shape[1]
+        out = m._decoder(hidden, 0, caches)
+        want = [m.lm_head(out[:, -1:, :])[:, -1].float().argmax(-1)]
+        for _ in range(steps - 1):
+            out = m._decoder(m.embed_tokens(want[-1][:, None]), pos, caches)
+            pos += 1
+            want.append(m.lm_head(out)[:, -1].float().argmax(-1))
+    assert torch.equal(got, torch.stack(want, dim=1))

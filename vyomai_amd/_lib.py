@@ -54,9 +54,11 @@ PROTOTYPES = {
     "vy_greedy_step": [_p, _i64, _i64, _i64, _i, _p, _i64, _i64, _p, _i64, _p, _i, _p, _p, _p],
     "vy_sampling_probs": [_p, _i64, _i64, _i64, _i, _f, _i, _f, _p, _i64, _p],
     "vy_decoder_step": [_p, _p, _i64, _p, _p, _p, _i64, _p],
+    "vy_gemma_decoder_step": [_p, _p, _i64, _p, _i64, _p],
     "vy_cast": [_p, _p, _i64, _i, _i, _p],
 }
-OTHER_SYMBOLS = ["vy_last_error", "vy_abi_version", "vy_layernorm_bwd_ws_rows", "vy_decode_ws_bytes"]
+OTHER_SYMBOLS = ["vy_last_error", "vy_abi_version", "vy_layernorm_bwd_ws_rows", "vy_decode_ws_bytes",
+                 "vy_gemma_ws_bytes"]
 ALL_SYMBOLS = list(PROTOTYPES) + OTHER_SYMBOLS
 
 

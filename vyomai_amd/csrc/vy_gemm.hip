@@ -1206,13 +1206,79 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// M <= 4 rows (single-sequence decode): a matrix-vector product is a pure weight stream.  One wave per
+// output column reads its weight row in 16-byte pieces -- a wave-instruction = 1 KiB contiguous, eight in
+// flight per lane -- against X from L2, v_dot2_f32_bf16 into one fp32 sum per row, wave reduction, scalar
+// epilogue.  N/4 workgroups whatever the shape: the 32-column MFMA kernel above has N/32, i.e. 64 for
+// a 16384 -> 2048 down-projection, a quarter of the chip.
+// ------------------------------------------------------------------------------------------
+template <int ACT, int MR>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx,
+                                                        const bf16* __restrict__ W, int64_t ldw, int M, int N, int K,
+                                                        EpiPlain<bf16> ep) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;   // wave-uniform
+  const bf16* w = W + (int64_t)n * ldw;
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  constexpr int U = 8;
+  for (int k0 = lane * 8; k0 < K; k0 += U * 512) {
+    bf16x8 wv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k0 + u * 512;
+      wv[u] = *reinterpret_cast<const bf16x8*>(w + (kk < K ? kk : 0));
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k0 + u * 512;
+      if (kk < K) {
+        union { bf16x8 v; bf16x2_t h[4]; } a, b;
+        a.v = wv[u];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+          if (m < M) {
+            b.v = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * ldx + kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_fdot2_f32_bf16(a.h[e], b.h[e], acc[m], false);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = vy_wave_sum(acc[m]);
+  if (lane < M && lane < MR) {
+    float x = 0.f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) x = lane == m ? acc[m] : x;
+    const int64_t m = lane;
+    if (ep.bias) x += (float)ep.bias[n];
+    if (ep.pre) ep.pre[m * ep.ldy + n] = (bf16)x;
+    x = vy_act_fwd<ACT>(x);
+    if (ep.residual) x += (float)ep.residual[m * ep.ldr + n];
+    if (ep.residual2) x += (float)ep.residual2[m * ep.ldr2 + n];
+    ep.y[m * ep.ldy + n] = (bf16)x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <int EPI, int ACT, bool GRAD>
 int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t M, int64_t N,
                 int64_t K, const EpiPlain<bf16>& ep, const EpiQkv<bf16>& eq, hipStream_t st) {
   static const int rot = [] { const char* e = getenv("VY_GEMM_ROT"); return e ? atoi(e) : 0; }();  // rotated k order: measured 1-5 % slower
-  if (M <= 32 && K % 16 == 0 && !GRAD && (EPI == 0 || !eq.rope || N % 64 == 0)) {
+  static const int gemv_on = [] { const char* e = getenv("VY_GEMV"); return e ? atoi(e) : 1; }();
+  if (M <= 4 && EPI == 0 && !GRAD && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && gemv_on &&
+      ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0)) {
+    if constexpr (EPI == 0 && !GRAD)
+      hipLaunchKernelGGL((gemv_bf16_kernel<ACT, 4>), dim3((unsigned)vy_cdiv(N, 4)), dim3(256), 0, st, X, ldx, W, ldw,
+                         (int)M, (int)N, (int)K, ep);
+  } else if (M <= 32 && K % 16 == 0 && !GRAD && (EPI == 0 || !eq.rope || N % 64 == 0)) {
     hipLaunchKernelGGL((gemm_skinny_bf16_kernel<EPI, ACT>), dim3((unsigned)vy_cdiv(N, 32)), dim3(256), 0, st, X, ldx,
                        W, ldw, (int)M, (int)N, (int)K, ep, eq);
   } else if (M <= 32) {  // skinny fallback: 32 x 128 tiles

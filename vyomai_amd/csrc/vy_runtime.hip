@@ -109,3 +109,57 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
   }
   return VY_OK;
 }
+
+extern "C" int64_t vy_gemma_ws_bytes(int32_t B, int32_t d, int32_t h, int32_t dh, int32_t ffn, int32_t dtype) {
+  const int64_t e = esize(dtype);
+  // normed input, q, attention output, two hidden buffers (x after attention / layer output), [gate|up], act
+  return 4 * up(B * (int64_t)d * e) + 2 * up(B * (int64_t)h * dh * e) + up(2 * B * (int64_t)ffn * e) +
+         up(B * (int64_t)ffn * e) + 4096;
+}
+
+extern "C" int vy_gemma_decoder_step(const vy_gemma_plan* p, const void* x, int64_t pos, void* logits, int64_t ldv,
+                                     void* stream) {
+  const char* who = "vy_gemma_decoder_step";
+  if (!p || !x || !p->layers || !p->ws || !logits) VY_FAIL(VY_ERR_ARG, "%s: null plan/input/workspace/output", who);
+  if (pos < 0) VY_FAIL(VY_ERR_ARG, "%s: negative position", who);
+  if (p->ws_bytes < vy_gemma_ws_bytes(p->B, p->d, p->h, p->dh, p->ffn, p->dtype)) VY_FAIL(VY_ERR_ARG, "%s: workspace too small", who);
+  const int64_t e = esize(p->dtype);
+  const int B = p->B, d = p->d, h = p->h, hk = p->hk, dh = p->dh, ffn = p->ffn;
+  char* w = (char*)p->ws;
+  void* n = w; w += up(B * (int64_t)d * e);
+  void* q = w; w += up(B * (int64_t)h * dh * e);
+  void* ao = w; w += up(B * (int64_t)h * dh * e);
+  void* x1 = w; w += up(B * (int64_t)d * e);
+  void* hb[2];
+  hb[0] = w; w += up(B * (int64_t)d * e);
+  hb[1] = w; w += up(B * (int64_t)d * e);
+  void* gu = w; w += up(2 * B * (int64_t)ffn * e);
+  void* act = w;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const void* cur = x;
+  int rc;
+  for (int l = 0; l < p->num_layers; ++l) {
+    const vy_gemma_layer& L = p->layers[l];
+    if ((rc = vy_rmsnorm_fwd(cur, d, L.ln_in, n, d, B, d, p->eps, 1.0f, p->dtype, stream))) return rc;
+    void* kdst = (char*)L.kcache + pos * L.c_sl * e;
+    void* vdst = (char*)L.vcache + pos * L.c_sl * e;
+    if ((rc = vy_qkv_rope_fwd_ex(n, d, L.wqkv, d, L.bqkv, p->cos_tab, p->sin_tab, pos, nullptr, q, (int64_t)h * dh, dh, dh,
+                                 kdst, L.c_sb, L.c_sh, L.c_sl, vdst, L.c_sb, L.c_sh, L.c_sl, B, 1, d, h, hk, dh, p->dtype,
+                                 stream))) return rc;
+    if ((rc = vy_attn_decode_ex(q, (int64_t)h * dh, dh, L.kcache, L.c_sb, L.c_sh, L.c_sl, L.vcache, L.c_sb, L.c_sh, L.c_sl,
+                                ao, (int64_t)h * dh, B, h, hk, pos + 1, nullptr, dh, scale, p->dtype, stream))) return rc;
+    if ((rc = vy_linear_fwd(ao, (int64_t)h * dh, L.wo, (int64_t)h * dh, L.bo, cur, d, x1, d, nullptr, B, d, (int64_t)h * dh,
+                            VY_ACT_NONE, p->dtype, stream))) return rc;
+    if ((rc = vy_rmsnorm_fwd(x1, d, L.ln_post, n, d, B, d, p->eps, 1.0f, p->dtype, stream))) return rc;
+    if ((rc = vy_linear_fwd(n, d, L.wgu, d, nullptr, nullptr, 0, gu, 2 * (int64_t)ffn, nullptr, B, 2 * (int64_t)ffn, d,
+                            VY_ACT_NONE, p->dtype, stream))) return rc;
+    if ((rc = vy_gated_act_fwd(gu, 2 * (int64_t)ffn, act, ffn, B, ffn, VY_ACT_GELU_TANH, p->dtype, stream))) return rc;
+    void* nxt = hb[l & 1];
+    if ((rc = vy_linear_fwd(act, ffn, L.wdown, ffn, nullptr, x1, d, nxt, d, nullptr, B, d, ffn, VY_ACT_NONE, p->dtype,
+                            stream))) return rc;
+    cur = nxt;
+  }
+  if ((rc = vy_rmsnorm_fwd(cur, d, p->norm_w, n, d, B, d, p->eps, 1.0f, p->dtype, stream))) return rc;
+  return vy_linear_fwd(n, d, p->head_w, d, nullptr, nullptr, 0, logits, ldv, nullptr, B, p->vocab, d, VY_ACT_NONE,
+                       p->dtype, stream);
+}

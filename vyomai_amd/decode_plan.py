@@ -143,3 +143,83 @@ class DecodePlan:
         hidden = torch.empty((self.batch, self.d), dtype=self.dtype, device=self.device) if want_hidden else None
         self._launch(x.data_ptr(), pos, None, _ptr(hidden), logits.data_ptr())
         return logits[:, : self.vocab], hidden
+
+
+# ---- Gemma-style stack (PaliGemma-shape language model, BASELINE configs[4]) ---------------------------
+
+class VyGemmaLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln_in", "ln_post", "wgu", "wdown", "kcache",
+                                          "vcache")] + [(n, C.c_int64) for n in ("c_sb", "c_sh", "c_sl")]
+
+
+class VyGemmaPlan(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_layers", "B", "d", "h", "hk", "dh", "ffn", "vocab", "dtype")] + \
+               [("eps", C.c_float), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
+                ("layers", C.POINTER(VyGemmaLayer)), ("norm_w", C.c_void_p), ("head_w", C.c_void_p),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+
+
+class GemmaDecodePlan:
+    """vy_gemma_plan of a models.paligemma.PaliGemmaForConditionalGeneration and its per-layer (k, v) cache
+    buffers: `step(x, pos)` runs one token through all layers, the final norm and the tied vocabulary
+    projection in ONE C call (vy_gemma_decoder_step)."""
+
+    def __init__(self, model, caches, batch: int):
+        from .models.paligemma import _packed
+        lib = _lib.load()
+        t = model.shape.text
+        dt = model.embed_tokens.weight.dtype
+        dev = model.embed_tokens.weight.device
+        self.keep = []
+
+        def ptr(x):
+            if x is None:
+                return None
+            x = x.detach()
+            assert x.dtype == dt and x.is_contiguous() and x.device == dev
+            self.keep.append(x)
+            return x.data_ptr()
+
+        layers = list(model.layers)
+        arr = (VyGemmaLayer * len(layers))()
+        for i, layer in enumerate(layers):
+            a, m = layer.self_attn, layer.mlp
+            wqkv, bqkv = _packed([a.q_proj, a.k_proj, a.v_proj], layer, "_qkv")
+            wgu, _ = _packed([m.gate_proj, m.up_proj], m, "_gu")
+            kc, vc = caches[i]
+            if kc.dtype != dt or kc.shape[0] < batch or kc.stride(3) != 1 or kc.stride() != vc.stride():
+                raise ValueError(f"cache buffers {tuple(kc.shape)} do not fit (B={batch})")
+            L = arr[i]
+            L.wqkv, L.bqkv = ptr(wqkv), ptr(bqkv)
+            L.wo, L.bo = ptr(a.o_proj.weight), ptr(a.o_proj.bias)
+            L.ln_in, L.ln_post = ptr(layer.input_layernorm.weight), ptr(layer.post_attention_layernorm.weight)
+            L.wgu, L.wdown = ptr(wgu), ptr(m.down_proj.weight)
+            L.kcache, L.vcache = kc.data_ptr(), vc.data_ptr()
+            L.c_sb, L.c_sh, L.c_sl = kc.stride(0), kc.stride(1), kc.stride(2)
+            self.keep += [kc, vc]
+        self.layers = arr
+        p = VyGemmaPlan()
+        p.num_layers, p.B, p.d = len(layers), batch, t.hidden_size
+        p.h, p.hk, p.dh = t.num_attention_heads, t.num_key_value_heads, t.head_dim
+        p.ffn, p.vocab, p.dtype, p.eps = t.intermediate_size, t.vocab_size, _lib.dtype_code(dt), t.rms_norm_eps
+        cos, sin = model.rope.on(dev)
+        self.keep += [cos, sin]
+        p.cos_tab, p.sin_tab = cos.data_ptr(), sin.data_ptr()
+        p.layers = C.cast(arr, C.POINTER(VyGemmaLayer))
+        p.norm_w, p.head_w = ptr(model.norm.weight), ptr(model.embed_tokens.weight)
+        lib.vy_gemma_ws_bytes.restype = C.c_int64
+        lib.vy_gemma_ws_bytes.argtypes = [C.c_int32] * 6
+        nbytes = lib.vy_gemma_ws_bytes(batch, p.d, p.h, p.dh, p.ffn, p.dtype)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        p.ws, p.ws_bytes = self.ws.data_ptr(), nbytes
+        self.plan, self.batch, self.d, self.dtype, self.device = p, batch, p.d, dt, dev
+        self.ldv = (t.vocab_size + 7) // 8 * 8
+        self.vocab = t.vocab_size
+
+    def step(self, x: torch.Tensor, pos: int) -> torch.Tensor:
+        """x: (B, d) scaled embeddings of the current token -> logits (B, vocab) view."""
+        assert x.shape == (self.batch, self.d) and x.dtype == self.dtype and x.is_contiguous()
+        logits = torch.empty((self.batch, self.ldv), dtype=self.dtype, device=self.device)
+        _lib.call("vy_gemma_decoder_step", C.byref(self.plan), x.data_ptr(), int(pos), logits.data_ptr(), self.ldv,
+                  torch.cuda.current_stream().cuda_stream)
+        return logits[:, : self.vocab]

@@ -253,15 +253,22 @@ class PaliGemmaForConditionalGeneration(nn.Module):
                   for _ in self.layers]
         pos = hidden.shape[1]
         out = self._decoder(hidden, 0, caches)
-        tokens = []
-        nxt = torch.topk(self.lm_head(out[:, -1:, :])[:, -1].float(), k=1, dim=-1)[1]
-        tokens.append(nxt)
-        for _ in range(max_new_tokens - 1):
-            out = self._decoder(self.embed_tokens(nxt), pos, caches)
-            pos += 1
-            nxt = torch.topk(self.lm_head(out)[:, -1].float(), k=1, dim=-1)[1]
-            tokens.append(nxt)
-        return torch.cat(tokens, dim=1)
+        # greedy loop: the first token comes from the prefill; every later one is ONE native call through the
+        # stack (vy_gemma_decoder_step) plus one for the pick (vy_greedy_step) -- no per-layer Python
+        tokens = torch.zeros((B, max_new_tokens), dtype=torch.long, device=dev)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)       # (the notebook's loop has no early stop)
+        no_stop = torch.tensor([-1], dtype=torch.long, device=dev)
+        first = self.lm_head(out[:, -1:, :])[:, -1]
+        ops.greedy_step_(first, tokens, 0, None, no_stop, done)
+        if max_new_tokens > 1:
+            from ..decode_plan import GemmaDecodePlan
+            plan = GemmaDecodePlan(self, caches, B)
+            scale = torch.tensor(t.hidden_size ** 0.5, dtype=dt, device=dev)
+            for i in range(1, max_new_tokens):
+                x = self.embed_tokens(tokens[:, i - 1]) * scale
+                ops.greedy_step_(plan.step(x.contiguous(), pos), tokens, i, None, no_stop, done)
+                pos += 1
+        return tokens
 
 
 def _angles(dim: int, max_pos: int, base: float) -> torch.Tensor:
