@@ -258,8 +258,15 @@ class FlatTrainer:
         self.arena.zero_grad()
         self.reducer.reset()
         self._stepped = set()
+        self._backward_calls = 0
 
     def backward(self, loss: torch.Tensor) -> None:
+        if self._side is not None and getattr(self, "_backward_calls", 0) >= 1:
+            # the per-bucket AdamW of the overlapped optimizer runs as soon as a bucket's gradients are final,
+            # i.e. during the FIRST backward pass after zero_grad()
+            raise RuntimeError("gradient accumulation over several backward passes needs "
+                               "FlatTrainer(..., overlap_optimizer=False)")
+        self._backward_calls = getattr(self, "_backward_calls", 0) + 1
         loss.backward()
 
     def _adamw(self, lo: int, hi: int, step: int) -> None:
