@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--attn", default="none", choices=["none", "gqa"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] side measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     return ap.parse_args()
 
@@ -275,10 +276,24 @@ def main():
         model.train()
 
     roof = cpu = None
+    others = None
     if rank == 0:
         roof = roofline_probe(cfg, B, L, dev)
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(cfg, L)
+        if world == 1 and not a.no_other_configs:
+            # the other BASELINE.json configurations, measured beside the headline (never part of `value`):
+            # the training model is released first; a failure here leaves a note, not a broken bench line
+            del trainer, model
+            torch.cuda.empty_cache()
+            others = {}
+            for key, mod in (("configs[3]", "tools.bench_vlm_training"), ("configs[4]", "tools.bench_paligemma")):
+                try:
+                    import importlib
+                    others[key] = importlib.import_module(mod).run()
+                except Exception as ex:   # noqa: BLE001
+                    others[key] = {"error": f"{type(ex).__name__}: {ex}"}
+                torch.cuda.empty_cache()
     if rank == 0:
         d = cfg.hidden_size
         fl_step = 3.0 * (block_flops_per_token(d, L) * cfg.num_hidden_layers + 2 * d * d + 2 * d * cfg.vocab_size) * B * L
@@ -298,6 +313,7 @@ def main():
             "decode": dec,
             "roofline": roof,
             "cpu_baseline": cpu,
+            "other_configs": others,
         }
         print(json.dumps(line))
     if world > 1:
