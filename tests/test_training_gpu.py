@@ -288,3 +288,38 @@ def test_grouped_weight_gradients_match_ungrouped():
     assert losses[True][-1] < losses[True][0]
     assert max(abs(x - y) for x, y in zip(losses[False], losses[True])) < 2e-2, (losses[False], losses[True])
     assert (finals[False] - finals[True]).abs().max().item() < 5e-3
+
+
+def test_vlm_caption_loss_matches_cross_entropy_of_the_logits():
+    """VisionLanguageModel.caption_loss (fused head + cross-entropy) against the captioning notebooks' loss on
+    the materialised logits: cross_entropy(logits[:, 1:-1], ids[:, 1:]); with a padding mask the padded targets
+    drop out."""
+    import vyomai_amd as V
+    from vyomai_amd.training import FlatTrainer
+    vcfg = cases.vit_cfg()
+    vcfg.num_hidden_layers = 1
+    if hasattr(vcfg, "hidden_dropout_prob"):
+        vcfg.hidden_dropout_prob = 0.0
+    cfg = cases.with_kv(cases.test_cfg(), None)
+    cfg.num_hidden_layers, cfg.hidden_dropout_prob, cfg.vocab_size = 2, 0.0, 3000
+    vlm = V.VisionLanguageModel(cfg, V.Vit(vcfg), "rope", None)
+    recipe.load_recipe_(vlm)
+    vlm = vlm.to(DEV).train()
+    FlatTrainer(vlm, lr=1e-4)      # bf16 compute dtype + shadows
+    img = T(recipe.uniform("cap.img", (3, 3, 224, 224), 0.5, 0.5)).to(DEV).to(BF)
+    ids = T(recipe.token_ids("cap.ids2", (3, 12), 3, cfg.vocab_size)).to(DEV)
+    with torch.no_grad():
+        logits = vlm(pixel_values=img, decoder_input_ids=ids).logits.float()
+    want = torch.nn.functional.cross_entropy(logits[:, 1:-1].reshape(-1, logits.shape[-1]), ids[:, 1:].reshape(-1))
+    got = vlm.caption_loss(img, ids)
+    assert abs(float(got) - float(want)) < 2e-2 * max(1.0, float(want)), (float(got), float(want))
+    am = torch.ones_like(ids)
+    am[1, 8:] = 0
+    with torch.no_grad():
+        lg = vlm(pixel_values=img, decoder_input_ids=ids, decoder_attention_mask=am).logits.float()
+    tgt = ids[:, 1:].clone()
+    tgt[am[:, 1:] == 0] = -100
+    want_m = torch.nn.functional.cross_entropy(lg[:, 1:-1].reshape(-1, lg.shape[-1]), tgt.reshape(-1), ignore_index=-100)
+    got_m = vlm.caption_loss(img, ids, am)
+    assert abs(float(got_m) - float(want_m)) < 2e-2 * max(1.0, float(want_m)), (float(got_m), float(want_m))
+    got_m.backward()

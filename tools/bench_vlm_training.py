@@ -23,9 +23,11 @@ def run(B: int = 64, steps: int = 4, dev: str = "cuda"):
     tr = FlatTrainer(vlm, lr=1e-4)
 
     def loss_fn():
-        logits = vlm(pixel_values=img, decoder_input_ids=ids).logits          # (B, 33, V): image token first
-        lg = logits[:, 1:-1].float().reshape(-1, logits.shape[-1])
-        return torch.nn.functional.cross_entropy(lg, ids[:, 1:].reshape(-1))
+        if os.environ.get("VLM_TORCH_LOSS"):
+            logits = vlm(pixel_values=img, decoder_input_ids=ids).logits          # (B, 33, V): image token first
+            lg = logits[:, 1:-1].float().reshape(-1, logits.shape[-1])
+            return torch.nn.functional.cross_entropy(lg, ids[:, 1:].reshape(-1))
+        return vlm.caption_loss(img, ids)     # the same loss with the head and the cross-entropy fused
 
     losses = []
     for s in range(2 + steps):

@@ -72,6 +72,8 @@ class VisionLanguageDecoderModel(nn.Module, PositionMixin):
                                                 start_pos=start_pos)
         for layer in self.all_layer:
             hidden_state = layer(hidden_state, mask, freqs=freqs, use_cache=use_cache, start_pos=start_pos)
+        if getattr(self, "_want_hidden", False):
+            return hidden_state
         return DecoderOutput(logits=self.lm_head(hidden_state))
 
     def create_mask_for_decoder(self, hidden_state: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
@@ -103,6 +105,25 @@ class VisionLanguageModel(nn.Module):
             encoder_output = self.encoder(pixel_values=pixel_values).logits[:, 0, :]
         return self.decoder(input_ids=decoder_input_ids, attention_mask=decoder_attention_mask,
                             encoder_hidden_state=encoder_output, use_cache=use_cache, start_pos=start_pos)
+
+    def caption_loss(self, pixel_values, decoder_input_ids, decoder_attention_mask=None,
+                     ignore_index: int = -100) -> torch.Tensor:
+        """Next-token loss of the caption with the LM head and the cross-entropy fused (no logits copy), the
+        training-side entry point like DecoderModel.clm_loss.  The decoder sees [image, t0 .. tn-1]; position p
+        predicts position p + 1, and the first caption token t0 (predicted from the image token alone) is not
+        scored -- the loss of the reference's captioning notebooks: cross_entropy(logits[:, 1:-1], ids[:, 1:])."""
+        self.decoder._want_hidden = True
+        try:
+            hidden = self.forward(pixel_values=pixel_values, decoder_input_ids=decoder_input_ids,
+                                  decoder_attention_mask=decoder_attention_mask)
+        finally:
+            self.decoder._want_hidden = False
+        B = decoder_input_ids.shape[0]
+        pad = torch.full((B, 2), ignore_index, dtype=decoder_input_ids.dtype, device=decoder_input_ids.device)
+        labels = torch.cat([pad, decoder_input_ids[:, 1:]], dim=1)      # aligned with [image, t0, t1, ...]
+        if decoder_attention_mask is not None:
+            labels[:, 2:] = labels[:, 2:].masked_fill(decoder_attention_mask[:, 1:] == 0, ignore_index)
+        return self.decoder.lm_head.loss(hidden, labels, ignore_index)
 
     def get_decoder(self) -> nn.Module:
         return self.decoder
