@@ -1272,6 +1272,7 @@ template <int EPI, int ACT, bool GRAD>
 int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t M, int64_t N,
                 int64_t K, const EpiPlain<bf16>& ep, const EpiQkv<bf16>& eq, hipStream_t st) {
   static const int rot = [] { const char* e = getenv("VY_GEMM_ROT"); return e ? atoi(e) : 0; }();  // rotated k order: measured 1-5 % slower
+  static const int mid_tiles = [] { const char* e = getenv("VY_GEMM_MID"); return e ? atoi(e) : 1; }();
   static const int gemv_on = [] { const char* e = getenv("VY_GEMV"); return e ? atoi(e) : 1; }();
   if (M <= 4 && EPI == 0 && !GRAD && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && gemv_on &&
       ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0)) {
@@ -1285,7 +1286,9 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 32);
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<32, 128, 1, 4, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                        st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
-  } else if (M <= 1024) {
+  } else if (M <= 1024 || (mid_tiles && vy_cdiv(M, 256) * vy_cdiv(N, 192) < 160)) {
+    // mid-size M: also whenever the 256 x 192 grid would leave more than a third of the CUs without a tile
+    // (M = 2112 rows of a captioning decoder x N = 768: 36 tiles of 256 x 192, 102 of 128 x 128)
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                        st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
