@@ -130,7 +130,7 @@ class _WgradGroup:
         if alpha is not None or not _GROUP_WGRADS:
             return False
         N, K = w.shape
-        return dy.numel() // N >= 4096 and N < 8192 and N * K >= 512 * 512 and K % 8 == 0
+        return dy.numel() // N >= _GROUP_MIN_ROWS and N < 8192 and N * K >= 512 * 512 and K % 8 == 0
 
     def add(self, dy, x, w, b) -> None:
         self.items.append((dy, x, w, b))
@@ -170,6 +170,7 @@ class _WgradGroup:
 
 
 _GROUP_WGRADS = os.environ.get("VY_WGRAD_GROUP", "1") != "0"
+_GROUP_MIN_ROWS = int(os.environ.get("VY_WGRAD_GROUP_ROWS", "2048"))   # measured on configs[3] (2112 decoder rows): -6 %
 _wgrad_group = _WgradGroup()
 
 
