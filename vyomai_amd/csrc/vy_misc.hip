@@ -709,7 +709,7 @@ extern "C" int vy_layernorm_fwd(const void* x, int64_t ldx, const void* gamma, c
   VY_FAIL(VY_ERR_ARG, "vy_layernorm_fwd: bad dtype %d", dtype);
 }
 
-// number of workgroups (= partial slab rows) of the LayerNorm backward: 4 waves each, 16 waves per
+// number of workgroups (= partial slab rows) of the LayerNorm backward: 4 waves each, 8 waves per
 // CU in flight at M = 16384 -- enough outstanding 16-byte loads to stream dy/x at the HBM rate
 extern "C" int vy_rmsnorm_fwd(const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int64_t M, int64_t N,
                               float eps, float w_offset, int dtype, void* stream) {
@@ -756,8 +756,9 @@ extern "C" int vy_gated_act_fwd(const void* gate_up, int64_t ldg, void* out, int
 }
 
 extern "C" int64_t vy_layernorm_bwd_ws_rows(int64_t M) {
+  static const int64_t cap = [] { const char* e = getenv("VY_LNBWD_WB"); return e ? (int64_t)atoi(e) : (int64_t)512; }();   // measured at M = 16384, N = 768: 256: 27.8 us, 512: 24.3, 1024: 27.6, 2048: 36.3
   const int64_t b = (M + 3) / 4;  // one wave per row at least
-  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+  return b < 1 ? 1 : (b > cap ? cap : b);
 }
 
 extern "C" int vy_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* gamma,
