@@ -170,6 +170,7 @@ class _WgradGroup:
 
 
 _GROUP_WGRADS = os.environ.get("VY_WGRAD_GROUP", "1") != "0"
+_DEFER_RESIDUALS = os.environ.get("VY_DEFER_RESIDUALS", "1") != "0"
 _GROUP_MIN_ROWS = int(os.environ.get("VY_WGRAD_GROUP_ROWS", "2048"))   # measured on configs[3] (2112 decoder rows): -6 %
 _wgrad_group = _WgradGroup()
 
@@ -211,7 +212,7 @@ def _defer_list(t: torch.Tensor):
 
 def defer_residual_grads(x: torch.Tensor) -> None:
     """Called by a post-LN transformer layer on its input (training only): see _defer_list."""
-    if torch.is_grad_enabled() and x.requires_grad:
+    if torch.is_grad_enabled() and x.requires_grad and _DEFER_RESIDUALS:
         x._vy_defer = []
 
 
