@@ -21,6 +21,7 @@ Extra objects on the JSON line:
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import math
 import os
@@ -216,7 +217,8 @@ def main():
 
     cfg = make_cfg(a)
     at = None if a.attn == "none" else "gqa"
-    model = V.DecoderModel(cfg, "rope", at)
+    with contextlib.redirect_stdout(sys.stderr):   # (the constructors print the reference's notices; stdout is the JSON line's)
+        model = V.DecoderModel(cfg, "rope", at)
     recipe.load_recipe_(model)
     model = model.to(dev).train()
     trainer = FlatTrainer(model, lr=5e-5, weight_decay=0.01)
@@ -290,7 +292,8 @@ def main():
             for key, mod in (("configs[3]", "tools.bench_vlm_training"), ("configs[4]", "tools.bench_paligemma")):
                 try:
                     import importlib
-                    others[key] = importlib.import_module(mod).run()
+                    with contextlib.redirect_stdout(sys.stderr):
+                        others[key] = importlib.import_module(mod).run()
                 except Exception as ex:   # noqa: BLE001
                     others[key] = {"error": f"{type(ex).__name__}: {ex}"}
                 torch.cuda.empty_cache()
