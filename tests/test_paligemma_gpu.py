@@ -152,3 +152,15 @@ def test_native_gemma_step_matches_the_layer_by_layer_loop():
             pos += 1
             want.append(m.lm_head(out)[:, -1].float().argmax(-1))
     assert torch.equal(got, torch.stack(want, dim=1))
+
+
+def test_generate_refuses_to_overrun_the_cache():
+    from vyomai_amd.models import paligemma as P
+    vis = P.SiglipVisionConfig(**dict(cases.SIGLIP, num_hidden_layers=1))
+    txt = types.SimpleNamespace(**dict(cases.GEMMA, num_hidden_layers=1, vocab_size=512, intermediate_size=512))
+    m = P.PaliGemmaForConditionalGeneration(P.PaliGemmaShape(vis, txt, txt.hidden_size)).to(DEV).to(torch.bfloat16).eval()
+    img = torch.rand(1, 3, 224, 224, device=DEV)
+    ids = torch.randint(3, 512, (1, 4), device=DEV)
+    with pytest.raises(ValueError):
+        m.generate(img, ids, max_new_tokens=50, max_cache_len=300)     # 260 prefix + 49 > 300
+    assert m.generate(img, ids, max_new_tokens=3, max_cache_len=300).shape == (1, 3)

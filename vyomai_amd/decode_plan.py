@@ -96,6 +96,7 @@ class DecodePlan:
         self.batch, self.d, self.vocab, self.dtype, self.device = batch, d, cfg.vocab_size, dtype, device
         self.ldv = (cfg.vocab_size + 7) // 8 * 8
         self.cache = cache
+        self.capacity = min(int(cache.key_cache[i].shape[2]) for i in range(len(layers)))
 
     # ---- hipGraph replay -------------------------------------------------------------------
     def graph_capable(self) -> bool:
@@ -130,6 +131,8 @@ class DecodePlan:
     def step(self, x: torch.Tensor, pos: int, want_hidden: bool = False):
         """x: (B, d) embeddings of the current token -> (logits (B, V) view, hidden (B, d) | None)."""
         assert x.shape == (self.batch, self.d) and x.dtype == self.dtype and x.is_contiguous()
+        if not 0 <= pos < self.capacity:   # the kernels write K/V at `pos` unchecked
+            raise ValueError(f"position {pos} exceeds the static cache size {self.capacity}")
         self.cache._seen_tokens = True
         if not want_hidden and self.graph_capable():
             if getattr(self, "graph", None) is None:
@@ -215,10 +218,13 @@ class GemmaDecodePlan:
         self.plan, self.batch, self.d, self.dtype, self.device = p, batch, p.d, dt, dev
         self.ldv = (t.vocab_size + 7) // 8 * 8
         self.vocab = t.vocab_size
+        self.capacity = min(int(kc.shape[2]) for kc, _ in caches)
 
     def step(self, x: torch.Tensor, pos: int) -> torch.Tensor:
         """x: (B, d) scaled embeddings of the current token -> logits (B, vocab) view."""
         assert x.shape == (self.batch, self.d) and x.dtype == self.dtype and x.is_contiguous()
+        if not 0 <= pos < self.capacity:   # the kernels write K/V at `pos` unchecked
+            raise ValueError(f"position {pos} exceeds the cache size {self.capacity} (max_cache_len)")
         logits = torch.empty((self.batch, self.ldv), dtype=self.dtype, device=self.device)
         _lib.call("vy_gemma_decoder_step", C.byref(self.plan), x.data_ptr(), int(pos), logits.data_ptr(), self.ldv,
                   torch.cuda.current_stream().cuda_stream)

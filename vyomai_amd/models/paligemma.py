@@ -248,6 +248,8 @@ class PaliGemmaForConditionalGeneration(nn.Module):
         img = ops.linear(self.vision_tower(pixel_values.to(dt)), self.multi_modal_projector.weight,
                          self.multi_modal_projector.bias)
         hidden = torch.cat([img, self.embed_tokens(input_ids)], dim=1)
+        if hidden.shape[1] + max_new_tokens - 1 > max_cache_len:
+            raise ValueError(f"{hidden.shape[1]} prefix tokens + {max_new_tokens} new tokens exceed max_cache_len={max_cache_len}")
         caches = [(torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev),
                    torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev))
                   for _ in self.layers]
