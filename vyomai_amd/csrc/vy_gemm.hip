@@ -19,6 +19,12 @@
 //
 // Reference semantics: nn.Linear call sites listed in include/vyom_hip.h.
 #include "vy_common.h"
+
+// (vy_misc.hip) RoPE on q and k in one launch
+int vy_rope_qk(void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl, int hq, void* k, int64_t k_sb, int64_t k_sh,
+               int64_t k_sl, int hk, const float* cos_tab, const float* sin_tab, int64_t pos0, int64_t B, int64_t L, int dh,
+               int dtype, hipStream_t st);
+
 #include <stdlib.h>
 
 namespace {
@@ -1464,8 +1470,8 @@ int qkv_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void*
   if (cos_tab && !fuse) {
     if (pos_dev) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: device-side position needs the fused RoPE path (bf16, dh == 64)", who);
     const int vdt = sizeof(T) == 2 ? VY_BF16 : VY_F32;
-    if (int rc = vy_rope_fwd(q, q_sb, q_sh, q_sl, cos_tab, sin_tab, pos0, B, h, L, dh, 0, vdt, st)) return rc;
-    if (int rc = vy_rope_fwd(k, k_sb, k_sh, k_sl, cos_tab, sin_tab, pos0, B, hk, L, dh, 0, vdt, st)) return rc;
+    if (int rc = vy_rope_qk(q, q_sb, q_sh, q_sl, h, k, k_sb, k_sh, k_sl, hk, cos_tab, sin_tab, pos0, B, L, dh, vdt,
+                            (hipStream_t)st)) return rc;
   }
   return VY_OK;
 }

@@ -345,6 +345,33 @@ __global__ void rope_kernel(T* __restrict__ x, int64_t sb, int64_t sh, int64_t s
   VyT<T>::st(p + i + half, rl<T>(bb * c) + rl<T>(a * s));
 }
 
+// q and k in ONE launch (the unfused QKV path of wide heads: Gemma dh = 256, SigLIP dh = 72): blockIdx.y picks
+// the tensor; same arithmetic as rope_kernel
+template <typename T>
+__global__ void rope2_kernel(T* __restrict__ xq, int64_t q_sb, int64_t q_sh, int64_t q_sl, int hq,
+                             T* __restrict__ xk, int64_t k_sb, int64_t k_sh, int64_t k_sl, int hk,
+                             const float* __restrict__ cos_tab, const float* __restrict__ sin_tab,
+                             int64_t pos0, int64_t B, int64_t L, int dh) {
+  const bool isk = blockIdx.y == 1;
+  T* x = isk ? xk : xq;
+  const int64_t sb = isk ? k_sb : q_sb, sh = isk ? k_sh : q_sh, sl = isk ? k_sl : q_sl;
+  const int heads = isk ? hk : hq;
+  const int half = dh >> 1;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * heads * L * half) return;
+  const int i = (int)(idx % half);
+  int64_t r = idx / half;
+  const int64_t l = r % L; r /= L;
+  const int hd = (int)(r % heads);
+  const int64_t b = r / heads;
+  T* p = x + b * sb + hd * sh + l * sl;
+  const float c = rl<T>(cos_tab[(pos0 + l) * half + i]);
+  const float s = rl<T>(sin_tab[(pos0 + l) * half + i]);
+  const float a = VyT<T>::ld(p + i), bb = VyT<T>::ld(p + i + half);
+  VyT<T>::st(p + i, rl<T>(a * c) + rl<T>(-bb * s));
+  VyT<T>::st(p + i + half, rl<T>(bb * c) + rl<T>(a * s));
+}
+
 // ---- cast / transpose / adamw -----------------------------------------------------------------
 template <typename S, typename D>
 __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
@@ -771,6 +798,24 @@ extern "C" int vy_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int
   if (dtype == VY_BF16) return ln_bwd_dispatch<bf16>(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dgamma, dbeta, beta, ws, M, N, st);
   if (dtype == VY_F32) return ln_bwd_dispatch<float>(dy, lddy, x, ldx, gamma, mean, rstd, dx, lddx, dgamma, dbeta, beta, ws, M, N, st);
   VY_FAIL(VY_ERR_ARG, "vy_layernorm_bwd: bad dtype %d", dtype);
+}
+
+// internal (vy_qkv_rope_fwd's unfused path): RoPE on q (hq heads) and k (hk heads) in one launch
+int vy_rope_qk(void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl, int hq, void* k, int64_t k_sb, int64_t k_sh,
+               int64_t k_sl, int hk, const float* cos_tab, const float* sin_tab, int64_t pos0, int64_t B, int64_t L, int dh,
+               int dtype, hipStream_t st) {
+  if (!q || !k || !cos_tab || !sin_tab || (dh & 1)) VY_FAIL(VY_ERR_ARG, "vy_rope_qk: bad arguments");
+  const int64_t total = B * (hq > hk ? hq : hk) * L * (dh / 2);
+  const dim3 grid((unsigned)vy_cdiv(total, 256), 2), block(256);
+  if (dtype == VY_BF16)
+    hipLaunchKernelGGL(rope2_kernel<bf16>, grid, block, 0, st, (bf16*)q, q_sb, q_sh, q_sl, hq, (bf16*)k, k_sb, k_sh, k_sl, hk,
+                       cos_tab, sin_tab, pos0, B, L, dh);
+  else if (dtype == VY_F32)
+    hipLaunchKernelGGL(rope2_kernel<float>, grid, block, 0, st, (float*)q, q_sb, q_sh, q_sl, hq, (float*)k, k_sb, k_sh, k_sl,
+                       hk, cos_tab, sin_tab, pos0, B, L, dh);
+  else VY_FAIL(VY_ERR_ARG, "vy_rope_qk: bad dtype %d", dtype);
+  VY_CHECK_LAUNCH("vy_rope_qk");
+  return VY_OK;
 }
 
 extern "C" int vy_rope_fwd(void* x, int64_t sb, int64_t sh, int64_t sl, const float* cos_tab,
