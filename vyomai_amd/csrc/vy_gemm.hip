@@ -1280,12 +1280,13 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
   static const int rot = [] { const char* e = getenv("VY_GEMM_ROT"); return e ? atoi(e) : 0; }();  // rotated k order: measured 1-5 % slower
   static const int mid_tiles = [] { const char* e = getenv("VY_GEMM_MID"); return e ? atoi(e) : 1; }();
   static const int gemv_on = [] { const char* e = getenv("VY_GEMV"); return e ? atoi(e) : 1; }();
+  static const int64_t skinny_max_n = [] { const char* e = getenv("VY_SKINNY_MAXN"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();   // wider (the vocabulary): 32 x 128 tiles with X staged once per workgroup -- 15.5 vs 31.1 us at N = 50265
   if (M <= 4 && EPI == 0 && !GRAD && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && gemv_on &&
       ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0)) {
     if constexpr (EPI == 0 && !GRAD)
       hipLaunchKernelGGL((gemv_bf16_kernel<ACT, 4>), dim3((unsigned)vy_cdiv(N, 4)), dim3(256), 0, st, X, ldx, W, ldw,
                          (int)M, (int)N, (int)K, ep);
-  } else if (M <= 32 && K % 16 == 0 && !GRAD && (EPI == 0 || !eq.rope || N % 64 == 0)) {
+  } else if (M <= 32 && K % 16 == 0 && !GRAD && (EPI == 0 || !eq.rope || N % 64 == 0) && N <= skinny_max_n) {
     hipLaunchKernelGGL((gemm_skinny_bf16_kernel<EPI, ACT>), dim3((unsigned)vy_cdiv(N, 32)), dim3(256), 0, st, X, ldx,
                        W, ldw, (int)M, (int)N, (int)K, ep, eq);
   } else if (M <= 32) {  // skinny fallback: 32 x 128 tiles
