@@ -397,12 +397,15 @@ template <> struct RowVec<float> {
   }
 };
 
-template <typename T, int CPR>  // CPR = dh / VEC lanes per key row, power of two <= 64
-__global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnParams p, int dh) {
+// NWV waves per workgroup: 4, or 16 for decode launches with few (batch x head) rows -- an MQA / small-batch
+// decode has only B*h workgroups, each walking its keys in dependent trips; four times the waves = a quarter
+// of the trips, combined through LDS as before (no workspace, no second launch)
+template <typename T, int CPR, int NWV = 4>  // CPR = dh / VEC lanes per key row, power of two <= 64
+__global__ __launch_bounds__(64 * NWV) void attn_rowwise_kernel(AttnParams p, int dh) {
   constexpr int VEC = RowVec<T>::VEC;
   constexpr int KPP = 64 / CPR;  // keys per wave pass
-  __shared__ float red_m[4 * KPP], red_l[4 * KPP];
-  __shared__ float red_o[4 * 64 * VEC];
+  __shared__ float red_m[NWV * KPP], red_l[NWV * KPP];
+  __shared__ float red_o[NWV * 64 * VEC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qi = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   const int kvh = head / (p.h / p.hk);
@@ -436,13 +439,13 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnParams p, int dh)
   // U key groups per trip: their K and V chunks are all requested before the first dot product,
   // so a wave keeps 2*U 16-byte loads in flight (decode is a pure HBM stream of the KV cache)
   constexpr int U = 4;
-  for (int j0 = wave * KPP; j0 < S_eff; j0 += 4 * KPP * U) {
+  for (int j0 = wave * KPP; j0 < S_eff; j0 += NWV * KPP * U) {
     float kv[U][VEC], vv[U][VEC], t[U];
     bool valid[U];
     int jc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int j = j0 + u * 4 * KPP + grp;
+      const int j = j0 + u * NWV * KPP + grp;
       valid[u] = j < S_eff;
       jc[u] = valid[u] ? j : S_eff - 1;
       RowVec<T>::load(Kb + (int64_t)jc[u] * p.k_sl + chl * VEC, kv[u]);
@@ -497,11 +500,11 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(AttnParams p, int dh)
   __syncthreads();
   if (wave == 0 && grp == 0 && ch_ok) {
     float M_ = red_m[0];
-    for (int w = 1; w < 4; ++w) M_ = fmaxf(M_, red_m[w * KPP]);
+    for (int w = 1; w < NWV; ++w) M_ = fmaxf(M_, red_m[w * KPP]);
     float Ls = 0.f, out[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) out[e] = 0.f;
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NWV; ++w) {
       const float a = __expf(red_m[w * KPP] - M_);
       Ls += red_l[w * KPP] * a;
 #pragma unroll
@@ -522,6 +525,15 @@ int launch_rowwise(const AttnParams& p, int dh, hipStream_t st, const char* who)
   int cpr = 1;
   while (cpr * VEC < dh) cpr <<= 1;  // lanes per key row, rounded up to a power of two
   const dim3 grid(p.L, p.h, p.B), block(256);
+  static const int wide_wg = [] { const char* e = getenv("VY_DECODE_WIDE_WG"); return e ? atoi(e) : 1; }();
+  static const int wide_rows = [] { const char* e = getenv("VY_DECODE_WIDE_ROWS"); return e ? atoi(e) : 128; }();
+  if (p.L == 1 && wide_wg && (int64_t)p.B * p.h <= wide_rows && p.S > 64 && std::is_same<T, bf16>::value && (cpr == 8 || cpr == 32)) {
+    const dim3 block16(1024);
+    if (cpr == 8) hipLaunchKernelGGL((attn_rowwise_kernel<T, 8, 16>), grid, block16, 0, st, p, dh);
+    else hipLaunchKernelGGL((attn_rowwise_kernel<T, 32, 16>), grid, block16, 0, st, p, dh);
+    VY_CHECK_LAUNCH(who);
+    return VY_OK;
+  }
 #define RW_GO(C) hipLaunchKernelGGL((attn_rowwise_kernel<T, C>), grid, block, 0, st, p, dh)
   switch (cpr) {
     case 1: RW_GO(1); break;
