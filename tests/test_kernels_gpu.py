@@ -100,7 +100,10 @@ def _qkv_ref(x, w, b, h, hk, dh, pos0, rope, dtype):
                                                (3, 50, 768, 12, 12, 64, False), (2, 1, 768, 12, 4, 64, True),
                                                (1, 40, 256, 2, 1, 128, True), (4, 300, 768, 12, 4, 64, True),
                                                (32, 1, 768, 12, 12, 64, True), (5, 1, 768, 12, 4, 64, False),
-                                               (3, 700, 768, 12, 12, 64, True)])
+                                               (3, 700, 768, 12, 12, 64, True),
+                                               # <= 4 rows without the fused rotary epilogue: the matrix-vector kernel
+                                               (1, 1, 2048, 8, 1, 256, True), (3, 1, 256, 2, 1, 128, False),
+                                               (4, 1, 768, 12, 4, 64, False), (2, 2, 1152, 16, 16, 72, False)])
 def test_qkv_rope(dtype, B, L, K, h, hk, dh, rope):
     ops, _ = _ops()
     pos0 = 5

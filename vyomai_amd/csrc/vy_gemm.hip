@@ -1218,10 +1218,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
 // epilogue.  N/4 workgroups whatever the shape: the 32-column MFMA kernel above has N/32, i.e. 64 for
 // a 16384 -> 2048 down-projection, a quarter of the chip.
 // ------------------------------------------------------------------------------------------
-template <int ACT, int MR>
+template <int EPI, int ACT, int MR>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx,
                                                         const bf16* __restrict__ W, int64_t ldw, int M, int N, int K,
-                                                        EpiPlain<bf16> ep) {
+                                                        EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1262,12 +1262,18 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
 #pragma unroll
     for (int m = 0; m < MR; ++m) x = lane == m ? acc[m] : x;
     const int64_t m = lane;
-    if (ep.bias) x += (float)ep.bias[n];
-    if (ep.pre) ep.pre[m * ep.ldy + n] = (bf16)x;
-    x = vy_act_fwd<ACT>(x);
-    if (ep.residual) x += (float)ep.residual[m * ep.ldr + n];
-    if (ep.residual2) x += (float)ep.residual2[m * ep.ldr2 + n];
-    ep.y[m * ep.ldy + n] = (bf16)x;
+    if constexpr (EPI == 0) {
+      if (ep.bias) x += (float)ep.bias[n];
+      if (ep.pre) ep.pre[m * ep.ldy + n] = (bf16)x;
+      x = vy_act_fwd<ACT>(x);
+      if (ep.residual) x += (float)ep.residual[m * ep.ldr + n];
+      if (ep.residual2) x += (float)ep.residual2[m * ep.ldr2 + n];
+      ep.y[m * ep.ldy + n] = (bf16)x;
+    } else {   // packed [q | k | v] projection without fused rotary: bias, head split, scatter
+      if (eq.bias) x += (float)eq.bias[n];
+      const int64_t b = m / eq.L, l = m - b * eq.L;
+      *qkv_dest(eq, b, l, n) = (bf16)x;
+    }
   }
 }
 
@@ -1281,11 +1287,11 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
   static const int mid_tiles = [] { const char* e = getenv("VY_GEMM_MID"); return e ? atoi(e) : 1; }();
   static const int gemv_on = [] { const char* e = getenv("VY_GEMV"); return e ? atoi(e) : 1; }();
   static const int64_t skinny_max_n = [] { const char* e = getenv("VY_SKINNY_MAXN"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();   // wider (the vocabulary): 32 x 128 tiles with X staged once per workgroup -- 15.5 vs 31.1 us at N = 50265
-  if (M <= 4 && EPI == 0 && !GRAD && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && gemv_on &&
+  if (M <= 4 && (EPI == 0 || !eq.rope) && !GRAD && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && gemv_on &&
       ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0)) {
-    if constexpr (EPI == 0 && !GRAD)
-      hipLaunchKernelGGL((gemv_bf16_kernel<ACT, 4>), dim3((unsigned)vy_cdiv(N, 4)), dim3(256), 0, st, X, ldx, W, ldw,
-                         (int)M, (int)N, (int)K, ep);
+    if constexpr (!GRAD && (EPI == 1 ? ACT == 0 : true))
+      hipLaunchKernelGGL((gemv_bf16_kernel<EPI, ACT, 4>), dim3((unsigned)vy_cdiv(N, 4)), dim3(256), 0, st, X, ldx, W, ldw,
+                         (int)M, (int)N, (int)K, ep, eq);
   } else if (M <= 32 && K % 16 == 0 && !GRAD && (EPI == 0 || !eq.rope || N % 64 == 0) && N <= skinny_max_n) {
     hipLaunchKernelGGL((gemm_skinny_bf16_kernel<EPI, ACT>), dim3((unsigned)vy_cdiv(N, 32)), dim3(256), 0, st, X, ldx,
                        W, ldw, (int)M, (int)N, (int)K, ep, eq);
