@@ -173,3 +173,71 @@ def test_recipe_is_deterministic_and_fp32_exact():
     ids = recipe.token_ids("t", (4, 9), 3, 50)
     assert ids.min() >= 3 and ids.max() < 50
     assert np.array_equal(recipe.param_value("lm_head.decoder.bias", (7,)), recipe.param_value("lm_head.bias", (7,)))
+
+
+def test_sampling_front_end_host_logic():
+    """Processors, cache trimming and the residual normalisation of speculative decoding: host behaviour that needs
+    no GPU -- and no CPU fallback for what does."""
+    import ctypes as C
+    from vyomai_amd import _lib, logits_processors as LP
+    from vyomai_amd.layers.kv_cache import DynamicCacheOne, StaticCacheOne
+    from vyomai_amd.speculative_decoding import norm_fn, trim_cache
+    with pytest.raises(TypeError):
+        LP.LogitsProcessor(1.0)                       # abstract in the reference (abc.ABC)
+    p = LP.TopKNucleusProcessor(0.9, 40, 0.8)
+    assert (p.temperature, p.top_k, p.top_p, p.stochastic) == (0.9, 40, 0.8, True)
+    assert isinstance(p, LP.MultinomialProcessor) and not LP.GreedyProcessor().stochastic
+    assert LP.GreedyProcessor().temperature == 1 and not hasattr(LP.GreedyProcessor(), "top_k")
+    with pytest.raises(_lib.VyomHipError, match="MI355X"):
+        LP.NucleusProcessor(0.2, 0.9)(torch.zeros(2, 16))   # CPU logits: no fallback
+    probs = torch.tensor([[0.1, 0.7, 0.2]])
+    assert LP.GreedyProcessor().sample(probs).tolist() == [[1]]
+    assert LP.MultinomialProcessor(1.0).sample(torch.tensor([[0.0, 1.0, 0.0]])).tolist() == [[1]]
+    # trim_cache (reference speculative_decoding.py:9-71): dynamic caches shrink, unknown types are refused
+    cfg = cases.micro_cfg()
+    cache = DynamicCacheOne(cfg)
+    k = torch.randn(1, 2, 6, 16)
+    cache.update(0, k, k.clone())
+    assert len(trim_cache(cache, 2)) == 4 and trim_cache(cache, 0) is cache and trim_cache(None, 3) is None
+    k2, _ = cache.update(0, k[:, :, :1], k[:, :, :1].clone())
+    assert k2.shape[2] == 5 and torch.equal(k2[:, :, 4], k[:, :, 0])
+    assert trim_cache(StaticCacheOne(cfg, max_cache_len=8, batch_size=1), 3) is not None
+    with pytest.raises(ValueError, match="Unsupported cache type"):
+        trim_cache([], 1)
+    x = torch.tensor([[0.5, -1.0, 1.5, float("nan")]])
+    assert torch.equal(norm_fn(x), torch.tensor([[0.25, 0.0, 0.75, 0.0]]))
+    # argument validation of the new entry points happens before any launch
+    buf = (C.c_char * 4096)()
+    a = (C.addressof(buf) + 15) // 16 * 16
+    with pytest.raises(_lib.VyomHipError, match="temperature"):
+        _lib.call("vy_sampling_probs", a, 64, 1, 8, 0, 0.0, 0, 0.0, a, 64, None)
+    with pytest.raises(_lib.VyomHipError, match="1..8 descriptors"):
+        _lib.call("vy_linear_wgrad_grouped", a, 0, 1, None)
+    with pytest.raises(_lib.VyomHipError, match="bad arguments"):
+        _lib.call("vy_greedy_step", a, 8, 1, 8, 0, a, 4, 9, None, 0, None, 0, a, None, None)   # cur_pos beyond the row
+
+
+def test_deferred_weight_gradient_bookkeeping():
+    """autograd_train._WgradGroup decides from shapes alone which weight gradients are deferred into a grouped
+    launch, and marks them so that the reducer ignores autograd's premature hook (training.BucketReducer._hook)."""
+    from vyomai_amd import autograd_train as AT
+    g = AT._WgradGroup()
+    w = torch.empty(768, 768)
+    assert g.wants(torch.empty(32, 512, 768), w, None)                 # 16384 rows
+    assert g.wants(torch.empty(2112, 768), w, None)                    # a captioning decoder's rows
+    assert not g.wants(torch.empty(1024, 768), w, None)                # too few rows for 256 x 256 tiles to pay
+    assert not g.wants(torch.empty(16384, 768), w, torch.ones(1))      # device-scalar alpha: the LM head's own path
+    assert not g.wants(torch.empty(16384, 50265), torch.empty(50265, 768), None)   # the vocabulary has its own variant
+    assert not g.wants(torch.empty(16384, 64), torch.empty(64, 64), None)
+    from vyomai_amd.training import BucketReducer
+    seen = []
+
+    class Fake:
+        mark_ready = lambda self, p: seen.append(p)
+    p = torch.nn.Parameter(torch.zeros(4))
+    p._vy_deferred = True
+    BucketReducer._hook(Fake(), p)
+    assert not seen
+    p._vy_deferred = False
+    BucketReducer._hook(Fake(), p)
+    assert seen == [p]
