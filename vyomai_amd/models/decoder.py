@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .._lib import VyomHipError
 from ..layers.attention import _SelfAttentionBase
 from ..layers.ffn import FeedForward
 from ..layers.kv_cache import DynamicCacheOne, StaticCacheOne
@@ -151,6 +152,9 @@ class DecoderModel(nn.Module, PositionMixin):
         last position.  The end-of-sequence bookkeeping stays on the device and is checked with
         one scalar read per token."""
         device = input_ids.device
+        if device.type != "cuda":
+            raise VyomHipError("vyomai_amd ops run on MI355X only: generate() got CPU token ids (no CPU fallback "
+                               "exists; move the model and its inputs to 'cuda')")
         bsz, prompt_len = input_ids.shape
         total = max_len + prompt_len
         pad_id = getattr(self.config, "pad_token_id", 1)
