@@ -261,6 +261,10 @@ class FlatTrainer:
         self._backward_calls = 0
 
     def backward(self, loss: torch.Tensor) -> None:
+        if self.reducer.world > 1 and getattr(self, "_backward_calls", 0) >= 1:
+            # a bucket is all-reduced as soon as its gradients are final, i.e. during the first backward pass
+            raise RuntimeError("gradient accumulation over several backward passes is not supported with more than "
+                               "one rank (the buckets are reduced during the first pass)")
         if self._side is not None and getattr(self, "_backward_calls", 0) >= 1:
             # the per-bucket AdamW of the overlapped optimizer runs as soon as a bucket's gradients are final,
             # i.e. during the FIRST backward pass after zero_grad()
