@@ -212,6 +212,14 @@ __device__ unsigned long long vy_gemm_clk[6];   // cycles, ticks, launches, prol
     atomicAdd(&vy_gemm_clk[2], 1ull);                                            \
   }
 
+// large-M kernel selection knob: VY_GEMM_VARIANT at first use, or vy_debug_set_gemm_variant() (tests and
+// same-process A/B timing; not part of include/vyom_hip.h).  -1 = the default selection.
+int g_gemm_variant = -2;
+inline int vy_gemm_variant() {
+  if (g_gemm_variant == -2) { const char* e = getenv("VY_GEMM_VARIANT"); g_gemm_variant = e ? atoi(e) : -1; }
+  return g_gemm_variant;
+}
+
 // XCD-aware bijective block remap: blocks b, b+8, ... share an XCD (round-robin dispatch), give
 // each XCD a contiguous run of tile ids.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -226,13 +234,17 @@ constexpr int BK = 64;            // k elements per stage
 constexpr int ROWB = BK * 2;      // bytes per LDS row (128)
 
 // ---- shared epilogue of the bf16 kernels ------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
+// PASSES > 1: the staged tile does not fit next to a second resident workgroup's LDS, so it goes out in
+// PASSES row bands of BM / PASSES rows (each band is owned by whole wave rows: WGM % PASSES == 0).
+template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD, int PASSES = 1>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM / (32 * WGM)], char* smem,
                                               int m0, int n0, int M, int N, const EpiPlain<bf16>& ep,
                                               const EpiQkv<bf16>& eq) {
   constexpr int NW = WGM * WGN, NT = 64 * NW;
   constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
   constexpr int EROW = BN * 2 + 16;
+  constexpr int RP = BM / PASSES;   // rows per pass
+  static_assert(WGM % PASSES == 0, "a pass must be whole wave rows");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
@@ -246,11 +258,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
   constexpr int CPR = BN / 8;  // 16-byte chunks per tile row
   char* et = smem;
 
+  const int my_pass = (wm * 32 * TM) / RP;   // the row band this wave's sub-tile belongs to
   auto stage_quad = [&](int row, int col, const float (&v)[4]) {
     bf16x4 w;
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = (bf16)v[e];
-    *reinterpret_cast<bf16x4*>(et + row * EROW + col * 2) = w;
+    *reinterpret_cast<bf16x4*>(et + (row - my_pass * RP) * EROW + col * 2) = w;
   };
   // bias of a register quad (depends on the lane half only); loaded at use, not kept live
   const bf16* biasp = EPI == 0 ? ep.bias : eq.bias;
@@ -271,10 +284,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
     // values -- what the reference's bf16 Linear -> GELU computes -- and, when the caller wants the
     // pre-activation saved for backward (dual), it is stored from the same chunk: one pass over the
     // tile, no second staging pass, no GELU chains among the accumulator registers.
-    auto flush_plain = [&](bf16* __restrict__ dst, bool final_pass, bool dual) {
-      for (int c = tid; c < BM * CPR; c += NT) {
+    auto flush_plain = [&](bf16* __restrict__ dst, bool final_pass, bool dual, int pass) {
+      for (int c = tid; c < RP * CPR; c += NT) {
         const int row = c / CPR, cc = c - row * CPR;
-        const int64_t m = m0 + row;
+        const int64_t m = m0 + pass * RP + row;
         const int n = n0 + cc * 8;
         if (m >= M || n >= N) continue;
         const bf16x8 sv = *reinterpret_cast<const bf16x8*>(et + row * EROW + cc * 16);
@@ -332,23 +345,27 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
       }
     };
     const bool dual = !GRAD && ep.pre != nullptr;   // (the GRAD path never sets ep.pre)
-    {
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+      if (PASSES == 1 || pass == my_pass) {
 #pragma unroll
-      for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          float bq[4];
-          bias_quad(n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, bq);
+          for (int rg = 0; rg < 4; ++rg) {
+            float bq[4];
+            bias_quad(n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, bq);
 #pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            float v[4];
+            for (int j = 0; j < TM; ++j) {
+              float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] + bq[e];
-            stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
+              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] + bq[e];
+              stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
+            }
           }
-        }
+      }
       __syncthreads();
-      flush_plain(ep.y, true, dual);
+      flush_plain(ep.y, true, dual, pass);
+      if (pass + 1 < PASSES) __syncthreads();
     }
   } else {
     // QKV: bias in registers; RoPE and the head-split scatter in phase 2, where a rotary pair
@@ -356,6 +373,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
     // are the bf16-rounded projections, so the rotation reproduces the reference's op order
     // (Linear output in q.dtype, then q*cos + rotate_half(q)*sin with every op rounded:
     // VyomAI/layers/positional_embeddings.py:173-181) exactly.
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+    if (PASSES == 1 || pass == my_pass) {
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -370,10 +390,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
           stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
         }
       }
+    }
     __syncthreads();
-    for (int c = tid; c < BM * CPR; c += NT) {
+    for (int c = tid; c < RP * CPR; c += NT) {
       const int row = c / CPR, cc = c - row * CPR;
-      const int64_t m = m0 + row;
+      const int64_t m = m0 + pass * RP + row;
       const int n = n0 + cc * 8;
       if (m >= M || n >= N) continue;
       const int64_t b = m / eq.L, l = m - b * eq.L;
@@ -400,6 +421,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
       } else {
         for (int e = 0; e < 8 && n + e < N; ++e) *qkv_dest(eq, b, l, n + e) = sv[e];
       }
+    }
+    if (pass + 1 < PASSES) __syncthreads();
     }
   }
 }
@@ -717,6 +740,168 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
   gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
   VY_CLK_MARK(2)
   VY_CLK_END()
+}
+
+// ------------------------------------------------------------------------------------------
+// 256 x 192 tile on FOUR waves (2 x 2, 128 x 96 per wave, 192 accumulator registers), k-slices of 32
+// with X in a three-deep and W in a two-deep LDS ring: 72 KiB, so TWO workgroups are resident per CU.
+// Why: with one 8-wave workgroup per CU every wave of the CU is in the same phase -- all issue their
+// LDS-DMA, all run MFMAs, all sit in the epilogue (bias / activation / staging / 128-byte stores,
+// 6-11 us at K = 768) while the matrix pipe idles.  Two independent workgroups drift apart: one's
+// epilogue, barrier waits and LDS-DMA issue run under the other's MFMAs (each SIMD hosts one wave of
+// each).  A wave's 128 x 96 sub-tile also needs fewer LDS bytes per FLOP (7 ds_read_b128 per 12 MFMAs
+// against 5 per 6).  Needs >= 2 tiles per CU to pay: used for N >= 2304 at large M.
+// ------------------------------------------------------------------------------------------
+template <int EPI, int ACT, bool GRAD, int VAR>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_pp_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+  constexpr int BM = 256, BN = 192, WGM = 2, WGN = 2, NW = 4;
+  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);   // 4, 3
+  constexpr int RK = 32, RROW = 64;
+  constexpr int PX = BM / 16, PW = BN / 16;          // 1-KiB pieces (16 rows x 64 B) per slice
+  constexpr int GX = PX / NW, GW = PW / NW;          // 4 and 3 per wave
+  static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
+  constexpr int XT = BM * RROW, WT = BN * RROW;      // 16 KiB, 12 KiB
+  constexpr int WOFF = 3 * XT;
+  constexpr int EROW = BN * 2 + 16;
+  constexpr int PASSES = 2;
+  constexpr int LDS_BYTES = 3 * XT + 2 * WT;
+  static_assert((BM / PASSES) * EROW <= LDS_BYTES, "epilogue band must fit in the ring");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // LDS-DMA through buffer descriptors: ONE per-lane byte offset per operand (row of the first piece,
+  // pre-swizzled 16-byte chunk); tile origin, piece and k-slice go into the scalar offset -- the 14
+  // pointer registers of the global_load form do not fit beside 192 accumulators.  The launcher only
+  // takes this kernel for whole tiles (M % 256 == 0, N % 192 == 0, K % 32 == 0, operands < 4 GiB).
+  const int lrow = lane >> 2, slot = lane & 3;
+  const int g = slot ^ ((lrow >> 2) & 3);   // (R >> 2) & 3 with R = 16 * piece + lrow
+  const unsigned xvoff = (unsigned)(((wave * 16 + lrow) * ldx + g * 8) * 2);
+  const unsigned wvoff = (unsigned)(((wave * 16 + lrow) * ldw + g * 8) * 2);
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(((int64_t)(M - 1) * ldx + K) * 2), 0x00020000);
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(unsigned)(((int64_t)(N - 1) * ldw + K) * 2), 0x00020000);
+  const unsigned xs0 = (unsigned)((int64_t)m0 * ldx * 2), ws0 = (unsigned)((int64_t)n0 * ldw * 2);
+  const unsigned xps = (unsigned)(NW * 16 * ldx * 2), wps = (unsigned)(NW * 16 * ldw * 2);   // piece stride
+  const int KT = K / RK;
+
+  auto stage_x = [&](int kt, int xb_idx) {
+    char* xb = smem + xb_idx * XT;
+    const unsigned so = xs0 + (unsigned)(kt * RK * 2);
+#pragma unroll
+    for (int t = 0; t < GX; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, xvoff, so + t * xps, 0, 0);
+  };
+  auto stage_w = [&](int kt) {
+    char* wb = smem + WOFF + (kt & 1) * WT;
+    const unsigned so = ws0 + (unsigned)(kt * RK * 2);
+#pragma unroll
+    for (int t = 0; t < GW; ++t)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, wvoff, so + t * wps, 0, 0);
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
+  unsigned xa[2], wa[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
+    xa[ks] = vy_lds_addr(smem) + (wm * 32 * TM + fr) * RROW + coff;
+    wa[ks] = vy_lds_addr(smem) + WOFF + (wn * 32 * TN + fr) * RROW + coff;
+  }
+  bf16x8 wf[TN], xf[TM];
+  auto read_w = [&](unsigned wbase) {
+    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; wf[i] = vy_lds_read128_off<i * 32 * RROW>(wbase); });
+  };
+  auto read_x = [&](unsigned xbase) {
+    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; xf[j] = vy_lds_read128_off<j * 32 * RROW>(xbase); });
+  };
+  auto tie_all = [&]() {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) vy_tie(wf[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) vy_tie(xf[j]);
+  };
+
+  // the wave's LDS-DMA queue, oldest first, at the wait that ends slice kt: X(kt+1), W(kt+1), X(kt+2)
+  stage_x(0, 0);
+  stage_w(0);
+  if (KT > 1) stage_x(1, 1);
+  if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  int xbuf = 0;   // kt % 3
+  for (int kt = 0; kt < KT; ++kt) {
+    const unsigned xo = xbuf * XT, wo = (kt & 1) * WT;
+    const int xnext2 = xbuf == 0 ? 2 : xbuf - 1;   // (kt + 2) % 3
+    if constexpr (VAR == 0) {
+      if (kt + 1 < KT) stage_w(kt + 1);
+      if (kt + 2 < KT) stage_x(kt + 2, xnext2);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        read_w(wa[ks] + wo);
+        read_x(xa[ks] + xo);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tie_all();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    } else {
+      // fragments of k-step 0 first, the LDS-DMA issue of the slices ahead in the shadow of its MFMAs;
+      // k-step 1's fragments are requested as soon as the registers they land in are free
+      read_w(wa[0] + wo);
+      read_x(xa[0] + xo);
+      if (kt + 1 < KT) stage_w(kt + 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tie_all();
+      __builtin_amdgcn_s_setprio(1);
+      vy_static_for<TM>([&](auto j_c) {
+        constexpr int j = decltype(j_c)::value;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        xf[j] = vy_lds_read128_off<j * 32 * RROW>(xa[1] + xo);
+      });
+      __builtin_amdgcn_s_setprio(0);
+      read_w(wa[1] + wo);
+      if (kt + 2 < KT) stage_x(kt + 2, xnext2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tie_all();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    xbuf = xbuf == 2 ? 0 : xbuf + 1;
+  }
+  // every wave has passed the last barrier after retiring its LDS reads: the ring is free
+  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD, PASSES>(acc, smem, m0, n0, M, N, ep, eq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1314,10 +1499,21 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     // Default (var < 0): N >= 3072 -> two-stage 256 x 256; otherwise 256 x 192 with the X operand in a
     // three-deep ring (gemm_nt_bf16_x3_kernel): equal or slightly slower on warm micro-benchmarks, +1 %
     // inside the training step where the activations come from HBM/MALL.  16 = the two-stage 256 x 192.
-    static const int var0 = [] { const char* e = getenv("VY_GEMM_VARIANT"); return e ? atoi(e) : -1; }();
-    const int var = var0 < 0 ? 14 : (var0 == 16 ? -1 : var0);
+    const int var0 = vy_gemm_variant();
+    int var = var0 < 0 ? 14 : (var0 == 16 ? -1 : var0);
     const bool wide = (N >= 3072);
-    if (var == 8 || (var < 0 && wide)) {
+    const bool pp_ok = M % 256 == 0 && N % 192 == 0 && K % 32 == 0 && M * ldx * 2 < (int64_t)0xffffffffll &&
+                       N * ldw * 2 < (int64_t)0xffffffffll;
+    static const int pp_min_n = [] { const char* e = getenv("VY_GEMM_PP_MIN_N"); return e ? atoi(e) : 0; }();
+    if ((var == 20 || var == 21) && !(pp_ok && N >= pp_min_n)) var = 14;
+    if (var == 20 || var == 21) {   // 4-wave 256 x 192 tiles, two workgroups per CU
+      if (var == 20)
+        hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI, ACT, GRAD, 0>), dim3(tm * tn), dim3(256), 0,
+                           st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+      else
+        hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI, ACT, GRAD, 1>), dim3(tm * tn), dim3(256), 0,
+                           st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
+    } else if (var == 8 || (var < 0 && wide)) {
       const int tn2 = (int)vy_cdiv(N, 256);
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
@@ -1528,6 +1724,8 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
 // y = LN(x W^T + bias + residual) for M <= 32 rows (decode), bf16: split-K GEMM + fused finish.
 // `part` is an fp32 scratch of vy_splitk_ws_floats(N) elements.  Internal to the decode driver.
 int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N; }
+
+extern "C" int vy_debug_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 
 // measurement aid, not part of include/vyom_hip.h: {shader cycles, 10 ns ticks, launches} since the last call
 extern "C" int vy_debug_gemm_clock(unsigned long long* out3) {   // out3: 6 values
