@@ -209,7 +209,33 @@ int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl,
  * p, m, v fp32 [n]; g fp32 [n]; p_bf16 (nullable) bf16 [n].  Matches torch.optim.AdamW. */
 int vy_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                  float grad_scale, void* stream);
+                  float grad_scale, const float* grad_scale_dev, void* stream);
+/* grad_scale_dev (nullable): one fp32 on the device multiplied into grad_scale by the kernel -- the
+ * clip_grad_norm_ coefficient min(1, max_norm / (norm + 1e-6)) of the reference's training loops
+ * (Examples/vyomai-fused-kernals-2t4.ipynb cell 0) without a host round trip. */
+
+/* out[0] = sum_i x[i]^2 over an fp32 arena (global gradient norm, same loops).  ws: >= 1024 floats of
+ * scratch.  Two launches, fixed summation order (run-to-run identical). */
+int vy_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dropout of the two hidden-state sites of a block.
+ * replaces: self.dropout(hidden_states) between dense and the residual add in AttentionSelfOutput
+ *   (VyomAI/layers/attention.py:55,69-71) and FeedForward (VyomAI/layers/ffn.py:24,37-39), p =
+ *   config.hidden_dropout_prob (VyomAI/utils.py:96, default 0.1), active in train().
+ * The keep mask is a pure function of (seed, offset, row, column) -- Philox4x32-7 on the counter
+ * {column / 8, row, offset}, sixteen bits per element, drop when below round(p * 65536) -- so the forward
+ * epilogue, the backward pass and a test all regenerate it; nothing is stored.
+ * vy_linear_dropout_fwd: Y = dropout(X . W^T + bias) / (1 - p) + residual   (vy_linear_fwd with the
+ *   mask applied in the epilogue, before the residual add).
+ * vy_dropout: y = x * keep / (1 - p) as its own pass over an [M, N] view (backward: the same mask on the
+ *   incoming gradient; x = ones gives the mask).
+ * ------------------------------------------------------------------------------------------ */
+int vy_linear_dropout_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                          const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int64_t N,
+                          int64_t K, float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream);
+int vy_dropout(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t N, float p_drop,
+               uint64_t seed, uint64_t offset, int dtype, void* stream);
 
 /* dx = dy * act'(pre), elementwise over [M,N] row-major views (GELU backward outside a GEMM). */
 int vy_act_bwd(const void* dy, int64_t lddy, const void* pre, int64_t ldpre, void* dx, int64_t lddx,
@@ -223,7 +249,7 @@ int vy_act_bwd(const void* dy, int64_t lddy, const void* pre, int64_t ldpre, voi
  * bwd: logits[m,:] <- (softmax(logits[m,:]) - onehot(label)) * (*gscale) / (*count), in place
  *      (rows with label == ignore become 0); gscale/count are device pointers: no host sync. */
 int vy_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, float* lse,
-                float* loss_sum, float* count, int64_t M, int64_t V, int dtype, void* stream);
+                float* loss_sum, float* count, int64_t M, int64_t V, int32_t* err_flag, int dtype, void* stream);
 int vy_xent_bwd(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, const float* lse,
                 const float* gscale, const float* count, int64_t M, int64_t V, int dtype, void* stream);
 /* Both in ONE pass over the logits (bf16, V <= 65536): `count` (device scalar: the number of rows
@@ -231,7 +257,10 @@ int vy_xent_bwd(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_
  * overwritten in place as in vy_xent_bwd.  The logits cross HBM once in each direction. */
 int vy_xent_fused(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, float* lse,
                   float* loss_sum, const float* count, const float* gscale, int64_t M, int64_t V,
-                  int dtype, void* stream);
+                  int32_t* err_flag, int dtype, void* stream);
+/* A label that is neither ignore_index nor inside [0, V) (torch.cross_entropy device-asserts on it) is
+ * never dereferenced: the row counts as ignored (zero loss, zero gradient) and *err_flag (nullable,
+ * device int32) is set to 1 for the host to report. */
 
 /* Token embedding (nn.Embedding: VyomAI/models/decoder.py:287, encoder.py:41, multimodel.py):
  * fwd: out[m,:] = table[ids[m],:] (bf16 or fp32).  Ids outside [0,V) give a zero row and set the

@@ -208,17 +208,21 @@ class Cfg:
         return cls(**kw)
 
 
-def attention_self_output(sd: SD, p: str, x: Tensor, residual: Tensor, eps: float) -> Tensor:
-    """AttentionSelfOutput: LN(dense(x) + residual), dropout is identity in eval.
-    layers/attention.py:57-72."""
+def attention_self_output(sd: SD, p: str, x: Tensor, residual: Tensor, eps: float,
+                          drop: Optional[Tensor] = None) -> Tensor:
+    """AttentionSelfOutput: LN(dropout(dense(x)) + residual); dropout is identity in eval.
+    layers/attention.py:57-72.  `drop` = keep mask already scaled by 1/(1-p) (what nn.Dropout multiplies
+    by in train(), :70), given explicitly so a test can use the mask the kernels generated."""
     y = linear(x, sd[p + "dense.weight"], sd.get(p + "dense.bias"))
+    if drop is not None:
+        y = y * drop.to(y.dtype)
     return layer_norm(y + residual, sd[p + "layernorm.weight"], sd[p + "layernorm.bias"], eps)
 
 
 def self_attention(sd: SD, p: str, cfg: Cfg, x: Tensor, mask: Optional[Tensor],
                    freqs: Optional[Tensor], gqa: bool, fused_qkv: bool = False,
                    cache=None, layer_idx: int = 0, start_pos: int = 0,
-                   fused_sdpa: bool = False) -> Tensor:
+                   fused_sdpa: bool = False, drop: Optional[Tensor] = None) -> Tensor:
     """Encoder/Decoder/Vision self-attention + AttentionSelfOutput.
 
     vanilla: layers/attention.py:99-133, 245-289; models/decoder.py:71-113
@@ -242,26 +246,30 @@ def self_attention(sd: SD, p: str, cfg: Cfg, x: Tensor, mask: Optional[Tensor],
         k, v = repeat_kv(k, n_rep), repeat_kv(v, n_rep)
     o = merge_heads(sdpa(q, k, v, mask, fused=fused_sdpa))
     eps = cfg.layer_norm_eps
-    return attention_self_output(sd, p + "out.", o, x, eps)
+    return attention_self_output(sd, p + "out.", o, x, eps, drop)
 
 
-def feed_forward(sd: SD, p: str, cfg: Cfg, x: Tensor, input_tensor: Tensor) -> Tensor:
-    """FeedForward: LN(W2 act(W1 x + b1) + b2 + input_tensor).  layers/ffn.py:32-40.
-    Width is 4*hidden (``multiplier``), not config.intermediate_size (:19-23)."""
+def feed_forward(sd: SD, p: str, cfg: Cfg, x: Tensor, input_tensor: Tensor,
+                 drop: Optional[Tensor] = None) -> Tensor:
+    """FeedForward: LN(dropout(W2 act(W1 x + b1) + b2) + input_tensor).  layers/ffn.py:32-40.
+    Width is 4*hidden (``multiplier``), not config.intermediate_size (:19-23).  `drop`: see
+    attention_self_output."""
     act = _ACT.get(cfg.hidden_act, gelu_erf)
     h = act(linear(x, sd[p + "intermediate.weight"], sd[p + "intermediate.bias"]))
     y = linear(h, sd[p + "out.weight"], sd[p + "out.bias"])
+    if drop is not None:
+        y = y * drop.to(y.dtype)
     return layer_norm(y + input_tensor, sd[p + "layernorm.weight"], sd[p + "layernorm.bias"],
                       cfg.layer_norm_eps)
 
 
 def block(sd: SD, p: str, cfg: Cfg, h: Tensor, mask, freqs, gqa: bool, fused_qkv=False,
-          cache=None, layer_idx=0, start_pos=0, fused_sdpa=False) -> Tensor:
+          cache=None, layer_idx=0, start_pos=0, fused_sdpa=False, drops=(None, None)) -> Tensor:
     """One layer: a = attn(h); return ffn(a, h) -- the FFN residual is the *layer input*
     (models/encoder.py:60-64, models/decoder.py:241-250, models/vision_encoder.py:49-53)."""
     a = self_attention(sd, p + "attention.", cfg, h, mask, freqs, gqa, fused_qkv, cache,
-                       layer_idx, start_pos, fused_sdpa)
-    return feed_forward(sd, p + "feed_forward.", cfg, a, h)
+                       layer_idx, start_pos, fused_sdpa, drops[0])
+    return feed_forward(sd, p + "feed_forward.", cfg, a, h, drops[1])
 
 
 def lm_head(sd: SD, p: str, cfg: Cfg, h: Tensor) -> Tensor:

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _lib.load().vy_abi_version() == 4
+    assert _lib.load().vy_abi_version() == 5
 
 
 def test_argument_errors_are_reported_without_a_gpu():

@@ -17,7 +17,7 @@ VY_F32, VY_BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
 MASK_NONE, MASK_CAUSAL, MASK_KEYPAD, MASK_ADDITIVE = 0, 1, 2, 4
 
-_p, _i64, _i, _f = C.c_void_p, C.c_int64, C.c_int, C.c_float
+_p, _i64, _i, _f, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64
 
 # name -> argtypes, exactly the prototypes of include/vyom_hip.h
 PROTOTYPES = {
@@ -42,11 +42,14 @@ PROTOTYPES = {
                     _p, _p, _i64, _i64, _p, _p,
                     _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,
                     _i, _i64, _p, _i64, _p, _p, _i64, _i64, _i, _i, _i64, _i64, _i, _f, _i, _p],
-    "vy_adamw_step": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p],
+    "vy_adamw_step": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p, _p],
+    "vy_sumsq": [_p, _i64, _p, _p, _p],
+    "vy_linear_dropout_fwd": [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _u64, _u64, _i, _p],
+    "vy_dropout": [_p, _i64, _p, _i64, _i64, _i64, _f, _u64, _u64, _i, _p],
     "vy_act_bwd": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _i, _i, _p],
-    "vy_xent_fwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
+    "vy_xent_fwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _i, _p],
     "vy_xent_bwd": [_p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _i, _p],
-    "vy_xent_fused": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i, _p],
+    "vy_xent_fused": [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _i, _p],
     "vy_transpose_batched": [_p, _i, _i, _i, _p],
     "vy_embedding_fwd": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p, _i, _p],
     "vy_embedding_bwd": [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _p],

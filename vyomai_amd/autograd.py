@@ -36,23 +36,36 @@ def _wants_grad(*ts) -> bool:
 # ------------------------------------------------------------------------------------------
 
 
-def linear_residual_layernorm(x, residual, w, b, ln_w, ln_b, eps):
+def _drop_args(p_drop: float, training: bool):
+    """(p, seed, offset) of one dropout call when the module is in train() with p > 0 (nn.Dropout's
+    condition in the reference: layers/attention.py:70, layers/ffn.py:38), else None."""
+    if not training or p_drop <= 0.0:
+        return None
+    from .rng import next_dropout
+    return next_dropout(p_drop)
+
+
+def linear_residual_layernorm(x, residual, w, b, ln_w, ln_b, eps, p_drop: float = 0.0, training: bool = False):
+    """LN(dropout(x W^T + b) + residual): AttentionSelfOutput (reference layers/attention.py:69-72)."""
+    drop = _drop_args(p_drop, training)
     if _wants_grad(x, residual, w, b, ln_w, ln_b):
         from .autograd_train import LinearResidualLayerNormFn
-        return LinearResidualLayerNormFn.apply(x, residual, w, b, ln_w, ln_b, eps)
+        return LinearResidualLayerNormFn.apply(x, residual, w, b, ln_w, ln_b, eps, drop)
     dt = x.dtype
-    s = ops.linear(x, _shadow(w, dt), _shadow(b, dt), residual=residual)
+    s = ops.linear(x, _shadow(w, dt), _shadow(b, dt), residual=residual, dropout=drop)
     y, _, _ = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps)
     return y
 
 
-def ffn_block(x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act):
+def ffn_block(x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act, p_drop: float = 0.0, training: bool = False):
+    """LN(dropout(act(x W1^T + b1) W2^T + b2) + residual): FeedForward (reference layers/ffn.py:32-40)."""
+    drop = _drop_args(p_drop, training)
     if _wants_grad(x, residual, w1, b1, w2, b2, ln_w, ln_b):
         from .autograd_train import FfnBlockFn
-        return FfnBlockFn.apply(x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act)
+        return FfnBlockFn.apply(x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act, drop)
     dt = x.dtype
     hmid = ops.linear(x, _shadow(w1, dt), _shadow(b1, dt), act=act)
-    s = ops.linear(hmid, _shadow(w2, dt), _shadow(b2, dt), residual=residual)
+    s = ops.linear(hmid, _shadow(w2, dt), _shadow(b2, dt), residual=residual, dropout=drop)
     y, _, _ = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps)
     return y
 
@@ -95,7 +108,7 @@ def self_attention_block(mod, x, attention_mask, freqs, cache, cache_index, star
         from .autograd_train import SelfAttentionFn
         o = SelfAttentionFn.apply(x, mod, attention_mask, freqs, start_pos, *mod._params())
         return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
-                                         aso.layernorm.bias, aso.layernorm.eps)
+                                         aso.layernorm.bias, aso.layernorm.eps, aso.dropout.p, aso.training)
     cos, sin, pos0 = resolve_freqs(freqs, dev)
     q = torch.empty((B, h, L, dh), dtype=dt, device=dev)
     if cache is not None:
@@ -106,7 +119,8 @@ def self_attention_block(mod, x, attention_mask, freqs, cache, cache_index, star
     else:
         kw = torch.empty((B, hk, L, dh), dtype=dt, device=dev)
         vw = torch.empty_like(kw)
-    ops.qkv_rope(x, _shadow(w, dt), _shadow(b, dt), h, hk, dh, cos, sin, pos0, q, kw, vw)
+    sw, sb = mod._packed_shadow(dt)
+    ops.qkv_rope(x, sw, sb, h, hk, dh, cos, sin, pos0, q, kw, vw)
     if cache is not None:
         k_all, v_all = cache.commit() if cache_index is None else cache.commit(cache_index)
     else:
@@ -117,7 +131,7 @@ def self_attention_block(mod, x, attention_mask, freqs, cache, cache_index, star
     else:
         o = ops.attention(q, k_all, v_all, **_mask_args(attention_mask, B, L, S, dev))
     return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
-                                     aso.layernorm.bias, aso.layernorm.eps)
+                                     aso.layernorm.bias, aso.layernorm.eps, aso.dropout.p, aso.training)
 
 
 def _split(x2: torch.Tensor, heads: int, dh: int) -> torch.Tensor:
@@ -142,7 +156,7 @@ def cross_attention_block(mod, x, enc, enc_mask, use_cache: bool):
         from .autograd_train import CrossAttentionFn
         o = CrossAttentionFn.apply(x, enc, mod, enc_mask, wq, bq, wk, bk, wv, bv)
         return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
-                                         aso.layernorm.bias, aso.layernorm.eps)
+                                         aso.layernorm.bias, aso.layernorm.eps, aso.dropout.p, aso.training)
 
     def project():
         k2 = ops.linear(enc, _shadow(wk, dt), _shadow(bk, dt))
@@ -163,5 +177,5 @@ def cross_attention_block(mod, x, enc, enc_mask, use_cache: bool):
     S = k.shape[2]
     o = ops.attention(q, k, v, **_mask_args(enc_mask, B, L, S, dev))
     return linear_residual_layernorm(o, x, aso.dense.weight, aso.dense.bias, aso.layernorm.weight,
-                                     aso.layernorm.bias, aso.layernorm.eps)
+                                     aso.layernorm.bias, aso.layernorm.eps, aso.dropout.p, aso.training)
 

@@ -249,14 +249,15 @@ class LinearResidualLayerNormFn(torch.autograd.Function):
     """y = LN(x W^T + b + residual).  AttentionSelfOutput (reference layers/attention.py:69-72)."""
 
     @staticmethod
-    def forward(ctx, x, residual, w, b, ln_w, ln_b, eps):
+    def forward(ctx, x, residual, w, b, ln_w, ln_b, eps, drop=None):
         _require_bf16(x)
         dt = x.dtype
-        s = ops.linear(x, _shadow(w, dt), _shadow(b, dt), residual=residual)
+        s = ops.linear(x, _shadow(w, dt), _shadow(b, dt), residual=residual, dropout=drop)
         y, mean, rstd = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
         ctx.save_for_backward(x, s, mean, rstd)
         ctx.params = (w, b, ln_w, ln_b)
         ctx.defer = _defer_list(residual)
+        ctx.drop = drop
         return y
 
     @staticmethod
@@ -265,25 +266,29 @@ class LinearResidualLayerNormFn(torch.autograd.Function):
         w, b, ln_w, ln_b = ctx.params
         dy = dy.contiguous()
         ds, dg, dbt = _ln_bwd(dy, s, ln_w, ln_b, mean, rstd)
-        dx = ops.linear_dgrad(ds, _wt(w, x.dtype))
-        dw, db = _wgrad(ds, x, w, b)
+        # dropout sits between the projection and the residual add: the projection's gradient is ds under
+        # the forward's mask (regenerated from (seed, offset)), the residual's is ds itself
+        dz = ops.dropout(ds, *ctx.drop) if ctx.drop is not None else ds
+        dx = ops.linear_dgrad(dz, _wt(w, x.dtype))
+        dw, db = _wgrad(dz, x, w, b)
         if ctx.defer is not None:      # the residual gradient rides to the QKV dgrad epilogue
             ctx.defer.append(ds)
             ds = None
-        return dx, ds, dw, db, dg, dbt, None
+        return dx, ds, dw, db, dg, dbt, None, None
 
 
 class FfnBlockFn(torch.autograd.Function):
     """y = LN(act(x W1^T + b1) W2^T + b2 + residual).  FeedForward (reference layers/ffn.py:32-40)."""
 
     @staticmethod
-    def forward(ctx, x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act):
+    def forward(ctx, x, residual, w1, b1, w2, b2, ln_w, ln_b, eps, act, drop=None):
         _require_bf16(x)
         dt = x.dtype
         pre = torch.empty((*x.shape[:-1], w1.shape[0]), dtype=dt, device=x.device)
         hmid = torch.empty_like(pre)
         ops.linear(x, _shadow(w1, dt), _shadow(b1, dt), act=act, pre_out=pre, out=hmid)
-        s = ops.linear(hmid, _shadow(w2, dt), _shadow(b2, dt), residual=residual)
+        s = ops.linear(hmid, _shadow(w2, dt), _shadow(b2, dt), residual=residual, dropout=drop)
+        ctx.drop = drop
         y, mean, rstd = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
         ctx.save_for_backward(x, pre, hmid, s, mean, rstd)
         ctx.params = (w1, b1, w2, b2, ln_w, ln_b)
@@ -298,14 +303,15 @@ class FfnBlockFn(torch.autograd.Function):
         dt = x.dtype
         dy = dy.contiguous()
         ds, dg, dbt = _ln_bwd(dy, s, ln_w, ln_b, mean, rstd)
-        dpre = ops.linear_dgrad(ds, _wt(w2, dt), pre=pre, act=ctx.act)  # (ds W2) * act'(pre)
-        dw2, db2 = _wgrad(ds, hmid, w2, b2)
+        dz = ops.dropout(ds, *ctx.drop) if ctx.drop is not None else ds   # the forward's mask (see above)
+        dpre = ops.linear_dgrad(dz, _wt(w2, dt), pre=pre, act=ctx.act)  # (dz W2) * act'(pre)
+        dw2, db2 = _wgrad(dz, hmid, w2, b2)
         dx = ops.linear_dgrad(dpre, _wt(w1, dt))
         dw1, db1 = _wgrad(dpre, x, w1, b1)
         if ctx.defer is not None:
             ctx.defer.append(ds)
             ds = None
-        return dx, ds, dw1, db1, dw2, db2, dg, dbt, None, None
+        return dx, ds, dw1, db1, dw2, db2, dg, dbt, None, None, None
 
 
 class SelfAttentionFn(torch.autograd.Function):
@@ -327,7 +333,8 @@ class SelfAttentionFn(torch.autograd.Function):
         q = torch.empty((B, h, L, dh), dtype=dt, device=dev)
         k = torch.empty((B, hk, L, dh), dtype=dt, device=dev)
         v = torch.empty_like(k)
-        ops.qkv_rope(x, _shadow(w, dt), _shadow(b, dt), h, hk, dh, cos, sin, pos0, q, k, v)
+        sw, sb = mod._packed_shadow(dt)
+        ops.qkv_rope(x, sw, sb, h, hk, dh, cos, sin, pos0, q, k, v)
         lse = torch.empty((B, h, L), dtype=torch.float32, device=dev)
         causal, kp, sp = False, None, 0
         if attention_mask is not None:
@@ -433,11 +440,7 @@ def _heads(x2: torch.Tensor, heads: int, dh: int) -> torch.Tensor:
 def _wt_packed(mod, w, dtype):
     """W^T of the packed projection: keyed on the versions of the member parameters."""
     return _wt_cached(mod, lambda m: tuple(p._version for p in m._params()) + (WEIGHT_EPOCH[0], dtype),
-                      lambda m: _shadow_packed(m, m._packed()[0], dtype))
-
-
-def _shadow_packed(mod, w, dtype):
-    return _shadow(w, dtype)
+                      lambda m: m._packed_shadow(dtype)[0])
 
 
 def _packed_wgrad(mod, dy, x, w, b, params):
@@ -544,7 +547,7 @@ class LMHeadLossFn(torch.autograd.Function):
     item 1).  Backward multiplies by the upstream gradient through the GEMMs (a device scalar)."""
 
     @staticmethod
-    def forward(ctx, hidden, labels, ignore_index, wd, bd, ln_w, ln_b, wv, bias, eps):
+    def forward(ctx, hidden, labels, ignore_index, wd, bd, ln_w, ln_b, wv, bias, eps, err_flag=None):
         _require_bf16(hidden)
         dt, dev = hidden.dtype, hidden.device
         B, L, _ = hidden.shape
@@ -569,9 +572,9 @@ class LMHeadLossFn(torch.autograd.Function):
             # one pass: loss AND the unit gradient (d loss / d logits for an upstream gradient of 1),
             # written over the logits; backward scales by the actual upstream gradient (linearity)
             acc[1] = (shifted != ignore_index).sum()
-            ops.xent_fused_(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2], _one(dev))
+            ops.xent_fused_(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2], _one(dev), err_flag)
         else:
-            ops.xent_fwd(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2])
+            ops.xent_fwd(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2], err_flag)
         ctx.save_for_backward(hidden, pre, g, n, mean, rstd, buf, shifted, lse, acc)
         ctx.params = (wd, bd, ln_w, ln_b, wv, bias)
         ctx.ignore = ignore_index
@@ -600,7 +603,7 @@ class LMHeadLossFn(torch.autograd.Function):
         dpre = _gelu_bwd(dg, pre)
         dh = ops.linear_dgrad(dpre, _wt(wd, dt))
         dwd, dbd = _wgrad(dpre, hidden, wd, bd)
-        return dh, None, None, dwd, dbd, dgam, dbet, dwv, dbias, None
+        return dh, None, None, dwd, dbd, dgam, dbet, dwv, dbias, None, None
 
 
 _ONES = {}

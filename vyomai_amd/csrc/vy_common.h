@@ -194,6 +194,48 @@ __device__ __forceinline__ float vy_round_bf16(float x) {
   return __builtin_bit_cast(float, (unsigned)u << 16);
 }
 
+// ---- dropout: counter-based keep mask ----------------------------------------------------------
+// nn.Dropout(hidden_dropout_prob) in AttentionSelfOutput / FeedForward (reference layers/attention.py:70,
+// layers/ffn.py:38).  The mask is a pure function of (seed, offset, row, column): Philox4x32-7 on the
+// counter {column / 8, row, offset} gives eight 16-bit lots for the eight columns of a 16-byte bf16
+// chunk; an element is dropped when its lot is below thr = round(p * 65536).  The forward epilogue,
+// vy_dropout (backward: the same mask on the incoming gradient) and the tests' mask export all call
+// this one function, so nothing has to be stored.
+struct VyDrop {
+  uint32_t thr;       // 0 = no dropout
+  float scale;        // 1 / (1 - p)
+  uint32_t seed_lo, seed_hi, off_lo, off_hi;
+};
+__host__ inline VyDrop vy_make_drop(float p, uint64_t seed, uint64_t offset) {
+  VyDrop d{};
+  if (p > 0.f) {
+    double t = (double)p * 65536.0 + 0.5;
+    d.thr = t >= 65536.0 ? 65536u : (uint32_t)t;
+    d.scale = p < 1.f ? 1.0f / (1.0f - p) : 0.f;
+    d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
+    d.off_lo = (uint32_t)offset; d.off_hi = (uint32_t)(offset >> 32);
+  }
+  return d;
+}
+__device__ __forceinline__ void vy_philox7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                           uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// the eight lots of the chunk holding columns 8 * chunk .. 8 * chunk + 7 of row m
+__device__ __forceinline__ void vy_drop_lots(const VyDrop& d, int64_t m, int chunk, uint32_t (&r)[4]) {
+  vy_philox7((uint32_t)chunk, (uint32_t)m, d.off_lo, d.off_hi ^ (uint32_t)((uint64_t)m >> 32), d.seed_lo, d.seed_hi, r);
+}
+__device__ __forceinline__ bool vy_drop_keep(const VyDrop& d, const uint32_t (&r)[4], int e) {   // e = column & 7
+  return ((r[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= d.thr;
+}
+
 // load/store helpers templated on the storage type
 template <typename T> struct VyT;
 template <> struct VyT<float> {

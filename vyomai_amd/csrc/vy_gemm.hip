@@ -59,7 +59,11 @@ template <> struct Quad<float> {
   }
 };
 
-// plain epilogue: (+bias) -> [save pre] -> act -> (* act'(gradpre)) -> (+residual) -> store
+template <typename T> __device__ __forceinline__ float round_like(float x);
+template <> __device__ __forceinline__ float round_like<bf16>(float x) { return vy_round_bf16(x); }
+template <> __device__ __forceinline__ float round_like<float>(float x) { return x; }
+
+// plain epilogue: (+bias) -> [save pre] -> act -> dropout -> (* act'(gradpre)) -> (+residual) -> store
 template <typename T>
 struct EpiPlain {
   const T* bias;
@@ -69,6 +73,7 @@ struct EpiPlain {
   T* y;   int64_t ldy;
   T* pre; // same ld as y
   int vec_ok;  // all row strides % 4 == 0 and base pointers 4-element aligned
+  VyDrop drop; // dropout on act(x W^T + b) before the residual add (thr == 0: none)
 };
 
 template <typename T, int ACT, bool GRAD>
@@ -84,6 +89,12 @@ __device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[
     if constexpr (!GRAD) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = vy_act_fwd<ACT>(v[i]);
+      if (e.drop.thr) {
+        uint32_t lots[4];
+        vy_drop_lots(e.drop, m, n >> 3, lots);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = vy_drop_keep(e.drop, lots, (n & 7) + i) ? round_like<T>(v[i]) * e.drop.scale : 0.f;
+      }
     } else {
       if (e.gradpre) { float g[4]; Quad<T>::load(e.gradpre + m * e.ldg + n, g);
 #pragma unroll
@@ -103,7 +114,14 @@ __device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[
       float x = v[i];
       if (e.bias) x += VyT<T>::ld(e.bias + n + i);
       if (e.pre) VyT<T>::st(e.pre + m * e.ldy + n + i, x);
-      if constexpr (!GRAD) x = vy_act_fwd<ACT>(x);
+      if constexpr (!GRAD) {
+        x = vy_act_fwd<ACT>(x);
+        if (e.drop.thr) {
+          uint32_t lots[4];
+          vy_drop_lots(e.drop, m, (n + i) >> 3, lots);
+          x = vy_drop_keep(e.drop, lots, (n + i) & 7) ? round_like<T>(x) * e.drop.scale : 0.f;
+        }
+      }
       else if (e.gradpre) x *= vy_act_grad<ACT>(VyT<T>::ld(e.gradpre + m * e.ldg + n + i));
       if (e.residual) x += VyT<T>::ld(e.residual + m * e.ldr + n + i);
       if (e.residual2) x += VyT<T>::ld(e.residual2 + m * e.ldr2 + n + i);
@@ -141,9 +159,6 @@ __device__ __forceinline__ T* qkv_dest(const EpiQkv<T>& e, int64_t b, int64_t l,
   return e.v + b * e.v_sb + hd * e.v_sh + l * e.v_sl + d;
 }
 
-template <typename T> __device__ __forceinline__ float round_like(float x);
-template <> __device__ __forceinline__ float round_like<bf16>(float x) { return vy_round_bf16(x); }
-template <> __device__ __forceinline__ float round_like<float>(float x) { return x; }
 
 // lo/hi: the two 32-column blocks of one 64-wide head (d = dlo..dlo+3 and d+32)
 template <typename T>
@@ -304,6 +319,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
         if constexpr (!GRAD && ACT != VY_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = vy_act_fwd_fast<ACT>(v[e]);
+        }
+        if constexpr (!GRAD) {
+          if (ep.drop.thr) {   // n is a multiple of 8: one Philox call covers the chunk
+            uint32_t lots[4];
+            vy_drop_lots(ep.drop, m, n >> 3, lots);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = vy_drop_keep(ep.drop, lots, e) ? v[e] * ep.drop.scale : 0.f;
+          }
         }
         if (ep.vec_ok && n + 8 <= N) {
           if (final_pass) {
@@ -1451,6 +1474,11 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
       if (ep.bias) x += (float)ep.bias[n];
       if (ep.pre) ep.pre[m * ep.ldy + n] = (bf16)x;
       x = vy_act_fwd<ACT>(x);
+      if (ep.drop.thr) {
+        uint32_t lots[4];
+        vy_drop_lots(ep.drop, m, n >> 3, lots);
+        x = vy_drop_keep(ep.drop, lots, n & 7) ? vy_round_bf16(x) * ep.drop.scale : 0.f;
+      }
       if (ep.residual) x += (float)ep.residual[m * ep.ldr + n];
       if (ep.residual2) x += (float)ep.residual2[m * ep.ldr2 + n];
       ep.y[m * ep.ldy + n] = (bf16)x;
@@ -1588,7 +1616,8 @@ template <typename T>
 int linear_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                 const void* residual, int64_t ldr, const void* gradpre, int64_t ldg, void* y,
                 int64_t ldy, void* pre_out, int64_t M, int64_t N, int64_t K, int act, bool grad,
-                hipStream_t st, const char* who, const void* residual2 = nullptr, int64_t ldr2 = 0) {
+                hipStream_t st, const char* who, const void* residual2 = nullptr, int64_t ldr2 = 0,
+                VyDrop drop = VyDrop{}) {
   if (int rc = check_operands<T>(who, x, ldx, w, ldw, M, N, K)) return rc;
   if (!y) VY_FAIL(VY_ERR_ARG, "%s: null output", who);
   if (ldy < N) VY_FAIL(VY_ERR_ARG, "%s: ldy < N", who);
@@ -1597,6 +1626,7 @@ int linear_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const vo
   ep.residual2 = (const T*)residual2; ep.ldr2 = ldr2;
   if (residual2 && !residual) VY_FAIL(VY_ERR_ARG, "%s: add_to2 without add_to", who);
   ep.gradpre = (const T*)gradpre; ep.ldg = ldg; ep.y = (T*)y; ep.ldy = ldy; ep.pre = (T*)pre_out;
+  ep.drop = drop;
   const int ve = 16 / (int)sizeof(T);  // elements per 16-byte access (bf16: 8, f32 quads: 4)
   ep.vec_ok = (ldy % ve == 0) && aligned_to(y, 16) && (!bias || aligned_to(bias, 4 * sizeof(T))) &&
               (!residual || (ldr % ve == 0 && aligned_to(residual, 16))) &&
@@ -1690,6 +1720,19 @@ extern "C" int vy_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t 
   if (dtype == VY_F32)
     return linear_impl<float>(x, ldx, w, ldw, bias, residual, ldr, nullptr, 0, y, ldy, pre_out, M, N, K, act, false, st, "vy_linear_fwd");
   VY_FAIL(VY_ERR_ARG, "vy_linear_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int vy_linear_dropout_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
+                                     const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int64_t N,
+                                     int64_t K, float p_drop, uint64_t seed, uint64_t offset, int dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!(p_drop >= 0.f && p_drop <= 1.f)) VY_FAIL(VY_ERR_ARG, "vy_linear_dropout_fwd: p=%g outside [0, 1]", (double)p_drop);
+  const VyDrop d = vy_make_drop(p_drop, seed, offset);
+  if (dtype == VY_BF16)
+    return linear_impl<bf16>(x, ldx, w, ldw, bias, residual, ldr, nullptr, 0, y, ldy, nullptr, M, N, K, VY_ACT_NONE, false, st, "vy_linear_dropout_fwd", nullptr, 0, d);
+  if (dtype == VY_F32)
+    return linear_impl<float>(x, ldx, w, ldw, bias, residual, ldr, nullptr, 0, y, ldy, nullptr, M, N, K, VY_ACT_NONE, false, st, "vy_linear_dropout_fwd", nullptr, 0, d);
+  VY_FAIL(VY_ERR_ARG, "vy_linear_dropout_fwd: bad dtype %d", dtype);
 }
 
 extern "C" int vy_linear_dgrad(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const void* pre,

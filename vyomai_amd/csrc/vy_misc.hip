@@ -13,7 +13,7 @@ void vy_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vy_last_error(void) { return g_err; }
-extern "C" int vy_abi_version(void) { return 4; }
+extern "C" int vy_abi_version(void) { return 5; }
 
 namespace {
 
@@ -460,7 +460,9 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const vy_transpo
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, bf16* __restrict__ pb, int64_t n, float lr, float b1,
-                             float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                             float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
+                             const float* __restrict__ gscale_dev) {
+  if (gscale_dev) gscale *= *gscale_dev;   // e.g. the gradient-clipping coefficient, computed on the device
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (; i < n; i += stride) {
@@ -536,12 +538,16 @@ template <typename T>
 __global__ __launch_bounds__(256) void xent_fwd_kernel(const T* __restrict__ logits, int64_t ld,
                                                        const int64_t* __restrict__ labels, int64_t ignore,
                                                        float* __restrict__ lse, float* __restrict__ loss_sum,
-                                                       float* __restrict__ count, int V) {
+                                                       float* __restrict__ count, int V, int* __restrict__ err) {
   constexpr int VEC = Chunk<T>::VEC;
   __shared__ float red[4];
   const int64_t m = blockIdx.x;
   const int64_t label = labels[m];
-  if (label == ignore) { if (threadIdx.x == 0) lse[m] = 0.f; return; }
+  // a label outside [0, V) that is not ignore_index (e.g. -100 padding under another ignore_index) would be
+  // an out-of-bounds read: the row is treated as ignored and the device error flag raised instead
+  const bool oob = label != ignore && (label < 0 || label >= V);
+  if (oob && err && threadIdx.x == 0) *err = 1;
+  if (label == ignore || oob) { if (threadIdx.x == 0) lse[m] = 0.f; return; }
   const T* row = logits + m * ld;
   const int nch = (V + VEC - 1) / VEC;
   float mx = -INFINITY, sm = 0.f;
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(256) void xent_bwd_kernel(T* __restrict__ logits, i
   const int64_t label = labels[m];
   T* row = logits + m * ld;
   const int nch = (V + VEC - 1) / VEC;
-  const bool dead = label == ignore;
+  const bool dead = label == ignore || label < 0 || label >= V;   // out-of-range labels: ignored rows (vy_xent_fwd flags them)
   const float sc = dead ? 0.f : (*gscale) / fmaxf(*count, 1.0f);
   const float l = lse[m];
   for (int c = threadIdx.x; c < nch; c += blockDim.x) {
@@ -602,7 +608,8 @@ __global__ __launch_bounds__(1024) void xent_fused_kernel(bf16* __restrict__ log
                                                           const int64_t* __restrict__ labels, int64_t ignore,
                                                           float* __restrict__ lse, float* __restrict__ loss_sum,
                                                           const float* __restrict__ count,
-                                                          const float* __restrict__ gscale, int V) {
+                                                          const float* __restrict__ gscale, int V,
+                                                          int* __restrict__ err) {
   constexpr int CPT = 8;  // 16-byte chunks per thread
   __shared__ float red[16];
   const int tid = threadIdx.x;
@@ -613,7 +620,9 @@ __global__ __launch_bounds__(1024) void xent_fused_kernel(bf16* __restrict__ log
   bf16x8 zero8;
 #pragma unroll
   for (int e = 0; e < 8; ++e) zero8[e] = (bf16)0.f;
-  if (label == ignore) {
+  const bool oob = label != ignore && (label < 0 || label >= V);   // see xent_fwd_kernel
+  if (oob && err && tid == 0) *err = 1;
+  if (label == ignore || oob) {
     for (int c = tid; c < nch; c += 1024) *reinterpret_cast<bf16x8*>(row + (int64_t)c * 8) = zero8;
     if (tid == 0) lse[m] = 0.f;
     return;
@@ -855,13 +864,14 @@ extern "C" int vy_act_bwd(const void* dy, int64_t lddy, const void* pre, int64_t
 }
 
 extern "C" int vy_xent_fwd(const void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, float* lse,
-                           float* loss_sum, float* count, int64_t M, int64_t V, int dtype, void* stream) {
+                           float* loss_sum, float* count, int64_t M, int64_t V, int32_t* err_flag, int dtype,
+                           void* stream) {
   if (!logits || !labels || !lse || !loss_sum || !count || M <= 0 || V <= 0) VY_FAIL(VY_ERR_ARG, "vy_xent_fwd: bad arguments");
   const int vec = dtype == VY_BF16 ? 8 : 4;
   if (ld % vec || ld < vy_cdiv(V, vec) * vec) VY_FAIL(VY_ERR_ARG, "vy_xent_fwd: row stride must be a multiple of %d and cover the padded row", vec);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == VY_BF16) hipLaunchKernelGGL(xent_fwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, st, (const bf16*)logits, ld, labels, ignore_index, lse, loss_sum, count, (int)V);
-  else if (dtype == VY_F32) hipLaunchKernelGGL(xent_fwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)logits, ld, labels, ignore_index, lse, loss_sum, count, (int)V);
+  if (dtype == VY_BF16) hipLaunchKernelGGL(xent_fwd_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, st, (const bf16*)logits, ld, labels, ignore_index, lse, loss_sum, count, (int)V, err_flag);
+  else if (dtype == VY_F32) hipLaunchKernelGGL(xent_fwd_kernel<float>, dim3((unsigned)M), dim3(256), 0, st, (const float*)logits, ld, labels, ignore_index, lse, loss_sum, count, (int)V, err_flag);
   else VY_FAIL(VY_ERR_ARG, "vy_xent_fwd: bad dtype %d", dtype);
   VY_CHECK_LAUNCH("vy_xent_fwd");
   return VY_OK;
@@ -882,13 +892,13 @@ extern "C" int vy_xent_bwd(void* logits, int64_t ld, const int64_t* labels, int6
 
 extern "C" int vy_xent_fused(void* logits, int64_t ld, const int64_t* labels, int64_t ignore_index, float* lse,
                              float* loss_sum, const float* count, const float* gscale, int64_t M, int64_t V,
-                             int dtype, void* stream) {
+                             int32_t* err_flag, int dtype, void* stream) {
   if (!logits || !labels || !lse || !loss_sum || !count || !gscale || M <= 0 || V <= 0) VY_FAIL(VY_ERR_ARG, "vy_xent_fused: bad arguments");
   if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_xent_fused: bf16 only (use vy_xent_fwd + vy_xent_bwd)");
   if (V > 65536) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_xent_fused: V=%ld exceeds the 65536 columns a workgroup keeps in registers (use vy_xent_fwd + vy_xent_bwd)", (long)V);
   if (ld % 8 || ld < vy_cdiv(V, 8) * 8 || (uintptr_t)logits % 16) VY_FAIL(VY_ERR_ARG, "vy_xent_fused: rows must be 16-byte aligned and cover the padded width");
   hipLaunchKernelGGL(xent_fused_kernel, dim3((unsigned)M), dim3(1024), 0, (hipStream_t)stream, (bf16*)logits, ld, labels,
-                     ignore_index, lse, loss_sum, count, gscale, (int)V);
+                     ignore_index, lse, loss_sum, count, gscale, (int)V, err_flag);
   VY_CHECK_LAUNCH("vy_xent_fused");
   return VY_OK;
 }
@@ -1014,7 +1024,7 @@ extern "C" int vy_transpose_batched(const vy_transpose_desc* descs_dev, int32_t 
 
 extern "C" int vy_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                             float grad_scale, void* stream) {
+                             float grad_scale, const float* grad_scale_dev, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0) VY_FAIL(VY_ERR_ARG, "vy_adamw_step: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const float bc1 = 1.0f - powf(beta1, (float)step);
@@ -1022,7 +1032,90 @@ extern "C" int vy_adamw_step(float* p, const float* g, float* m, float* v, void*
   const int64_t want = vy_cdiv(n, 1024);
   const dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
   hipLaunchKernelGGL(adamw_kernel, grid, block, 0, st, p, g, m, v, (bf16*)p_bf16, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2s, grad_scale);
+                     weight_decay, bc1, bc2s, grad_scale, grad_scale_dev);
   VY_CHECK_LAUNCH("vy_adamw_step");
+  return VY_OK;
+}
+
+// ---- sum of squares of an fp32 arena (global gradient norm for clip_grad_norm_) ----------------
+// Two launches, no atomics: run-to-run identical.  ws: >= 1024 floats.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ ws) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    if (i + 3 < n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+      acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    } else {
+      for (int e = 0; e < 4 && i + e < n; ++e) acc += x[i + e] * x[i + e];
+    }
+  }
+  acc = vy_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ ws, int nparts, float* __restrict__ out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) acc += (double)ws[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (float)(red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int vy_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream) {
+  if (!x || !out || !ws || n <= 0) VY_FAIL(VY_ERR_ARG, "vy_sumsq: bad arguments");
+  if ((uintptr_t)x % 16) VY_FAIL(VY_ERR_ARG, "vy_sumsq: x must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = vy_cdiv(n, 1024 * 8);
+  const int nparts = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nparts), dim3(256), 0, st, x, n, ws);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nparts, out);
+  VY_CHECK_LAUNCH("vy_sumsq");
+  return VY_OK;
+}
+
+// ---- dropout as its own pass: y = x * keep(seed, offset, row, column) / (1 - p) ------------------
+// The forward applies the mask inside the GEMM epilogue (vy_linear_dropout_fwd); backward applies the SAME
+// mask to the incoming gradient here before the dgrad / wgrad GEMMs (their operands go to LDS by DMA and
+// cannot be transformed on the way).  With x = ones this is the mask itself (tests).
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                                      int64_t M, int N, VyDrop d) {
+  const int nch = (N + 7) / 8;
+  const int64_t total = M * nch;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = c / nch;
+    const int ch = (int)(c - m * nch);
+    uint32_t lots[4];
+    vy_drop_lots(d, m, ch, lots);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int n = ch * 8 + e;
+      if (n < N) {
+        const float v = VyT<T>::ld(x + m * ldx + n);
+        VyT<T>::st(y + m * ldy + n, vy_drop_keep(d, lots, e) ? v * d.scale : 0.f);
+      }
+    }
+  }
+}
+extern "C" int vy_dropout(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t M, int64_t N, float p_drop,
+                          uint64_t seed, uint64_t offset, int dtype, void* stream) {
+  if (!x || !y || M <= 0 || N <= 0 || ldx < N || ldy < N) VY_FAIL(VY_ERR_ARG, "vy_dropout: bad arguments");
+  if (!(p_drop >= 0.f && p_drop <= 1.f)) VY_FAIL(VY_ERR_ARG, "vy_dropout: p=%g outside [0, 1]", (double)p_drop);
+  if (N > INT32_MAX) VY_FAIL(VY_ERR_ARG, "vy_dropout: N too large");
+  hipStream_t st = (hipStream_t)stream;
+  VyDrop d = vy_make_drop(p_drop, seed, offset);
+  if (d.thr == 0) d.scale = 1.0f;   // p == 0: plain copy
+  const int64_t want = vy_cdiv(M * vy_cdiv(N, 8), 256);
+  const dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
+  if (dtype == VY_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, grid, block, 0, st, (const bf16*)x, ldx, (bf16*)y, ldy, M, (int)N, d);
+  else if (dtype == VY_F32) hipLaunchKernelGGL(dropout_kernel<float>, grid, block, 0, st, (const float*)x, ldx, (float*)y, ldy, M, (int)N, d);
+  else VY_FAIL(VY_ERR_ARG, "vy_dropout: bad dtype %d", dtype);
+  VY_CHECK_LAUNCH("vy_dropout");
   return VY_OK;
 }

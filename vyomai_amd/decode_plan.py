@@ -55,7 +55,10 @@ class DecodePlan:
         arr = (VyDecodeLayer * len(layers))()
         for i, layer in enumerate(layers):
             att, ff = layer.attention, layer.feed_forward
-            w, b = att._packed()
+            pw, pb = att._packed_shadow(dtype)
+            for t_ in (pw, pb):
+                if t_ is not None:
+                    self.keep.append(t_)
             kc, vc = cache.key_cache[i], cache.value_cache[i]
             if kc.dtype != dtype or kc.device != torch.device(device):
                 cache.key_cache[i] = kc = kc.to(device=device, dtype=dtype)
@@ -63,7 +66,7 @@ class DecodePlan:
             if kc.shape[1] != hk or kc.shape[0] < batch or kc.stride(3) != 1:
                 raise ValueError(f"cache shape {tuple(kc.shape)} does not fit (B={batch}, kv heads={hk})")
             L = arr[i]
-            L.wqkv, L.bqkv = sh(w), sh(b)
+            L.wqkv, L.bqkv = _ptr(pw), _ptr(pb)
             L.wo, L.bo = sh(att.out.dense.weight), sh(att.out.dense.bias)
             L.ln1_w, L.ln1_b = sh(att.out.layernorm.weight), sh(att.out.layernorm.bias)
             L.w1, L.b1 = sh(ff.intermediate.weight), sh(ff.intermediate.bias)

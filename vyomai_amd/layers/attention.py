@@ -34,23 +34,37 @@ def repeat_kv(hidden_states: torch.Tensor, n_rep: int) -> torch.Tensor:
 repeat_kv_einops = repeat_kv
 
 
-def _check_dropout(module: nn.Module, p: float) -> None:
-    if module.training and p > 0.0:
-        raise NotImplementedError(
-            "vyomai_amd kernels do not implement dropout yet: use model.eval() or "
-            "hidden_dropout_prob=0.0 for training (SURVEY.md section 7, dropout note)")
+def _cast_into(dst: torch.Tensor, src: torch.Tensor) -> None:
+    """dst <- src (dtype conversion), in place: dst may be a view of the trainer's shadow arena."""
+    src = src.detach()
+    if src.is_cuda and src.is_contiguous() and dst.is_contiguous():
+        ops.cast(src, dst)
+    else:
+        with torch.no_grad():
+            dst.copy_(src)
 
 
 def _shadow(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Parameter in the compute dtype.  fp32 master weights with bf16 activations use a cached
-    bf16 copy, refreshed when the parameter changes (the trainer writes these copies itself)."""
+    bf16 copy, refreshed when the parameter changes.  A cache entry is (version, tensor, pinned):
+    `pinned` copies are views of the trainer's shadow arena (the fused AdamW kernel rewrites them
+    without touching tensor versions) and are refreshed IN PLACE when somebody else writes the
+    parameter (load_state_dict, re-initialisation) -- replacing them by a detached copy would leave
+    the model reading weights the optimizer no longer updates."""
     if param is None or param.dtype == dtype:
         return param
     cache = getattr(param, "_vy_shadow", None)
     ver = param._version
-    if cache is None or cache[0] != ver or cache[1].dtype != dtype or cache[1].device != param.device:
-        cache = (ver, param.detach().to(dtype))
-        param._vy_shadow = cache
+    if cache is not None and cache[1].dtype == dtype and cache[1].device == param.device \
+            and cache[1].shape == param.shape:
+        if cache[0] == ver:
+            return cache[1]
+        if len(cache) > 2 and cache[2]:
+            _cast_into(cache[1], param)
+            param._vy_shadow = (ver, cache[1], True)
+            return cache[1]
+    cache = (ver, param.detach().to(dtype), False)
+    param._vy_shadow = cache
     return cache[1]
 
 
@@ -65,10 +79,10 @@ class AttentionSelfOutput(nn.Module):
         self.dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_states: torch.Tensor, input_tensor: torch.Tensor) -> torch.Tensor:
-        _check_dropout(self, self.dropout.p)
         from ..autograd import linear_residual_layernorm
         return linear_residual_layernorm(hidden_states, input_tensor, self.dense.weight, self.dense.bias,
-                                         self.layernorm.weight, self.layernorm.bias, self.layernorm.eps)
+                                         self.layernorm.weight, self.layernorm.bias, self.layernorm.eps,
+                                         self.dropout.p, self.training)
 
 
 class _SelfAttentionBase(nn.Module):
@@ -160,6 +174,34 @@ class _SelfAttentionBase(nn.Module):
                 off += b.shape[0]
         return self._packed_w, self._packed_b
 
+    def _packed_shadow(self, dtype: torch.dtype) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """_packed() in the compute dtype.  The packed buffer has a version counter of its own that
+        in-place writes to query/key/value.weight (optimizer.step() of a torch optimizer,
+        load_state_dict) never bump, so the copy is keyed on the MEMBER parameters' versions (as the
+        transposed copy for the backward GEMMs is).  Entry: (key, w, b, packed data_ptr, pinned);
+        pinned = views of the trainer's shadow arena, refreshed in place (see _shadow)."""
+        w, b = self._packed()
+        if w.dtype == dtype:
+            return w, b
+        if self._fused_qkv:
+            return _shadow(w, dtype), _shadow(b, dtype)
+        key = tuple(p._version for p in self._params())
+        c = getattr(self, "_vy_pshadow", None)
+        if c is not None and c[1].dtype == dtype and c[1].device == w.device and c[3] == w.data_ptr() \
+                and (c[2] is None) == (b is None):
+            if c[0] == key:
+                return c[1], c[2]
+            if c[4]:
+                _cast_into(c[1], w)
+                if b is not None:
+                    _cast_into(c[2], b)
+                self._vy_pshadow = (key, c[1], c[2], c[3], True)
+                return c[1], c[2]
+        sw = w.detach().to(dtype)
+        sb = None if b is None else b.detach().to(dtype)
+        self._vy_pshadow = (key, sw, sb, w.data_ptr(), False)
+        return sw, sb
+
     def _params(self):
         if self._fused_qkv:
             return [self.qkv.weight, self.qkv.bias]
@@ -171,7 +213,6 @@ class _SelfAttentionBase(nn.Module):
     def _attend(self, hidden_state: torch.Tensor, attention_mask, freqs, cache=None,
                 cache_index: Optional[int] = None, start_pos: int = 0) -> torch.Tensor:
         from ..autograd import self_attention_block
-        _check_dropout(self, self.out.dropout.p)
         if not hidden_state.is_cuda:
             raise VyomHipError("vyomai_amd attention runs on MI355X only (got a CPU tensor; there is "
                                "no CPU fallback -- the CPU restatement lives in oracle/ for tests)")
@@ -256,7 +297,6 @@ class _CrossAttentionBase(_SelfAttentionBase):
         AttentionSelfOutput with `hidden_state` as residual.  `encoder_attention_mask` is a key-padding
         descriptor (AttnMask) or the reference's additive (B,1,1,S) tensor."""
         from ..autograd import cross_attention_block
-        _check_dropout(self, self.out.dropout.p)
         if not hidden_state.is_cuda:
             raise VyomHipError("vyomai_amd attention runs on MI355X only (got a CPU tensor; there is "
                                "no CPU fallback -- the CPU restatement lives in oracle/ for tests)")

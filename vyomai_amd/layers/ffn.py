@@ -2,8 +2,8 @@
 LN(dropout(out(act(intermediate(x)))) + input_tensor), width multiplier*hidden (NOT
 config.intermediate_size, like the reference :19-23).
 
-MI355X: two MFMA GEMM launches -- bias+GELU in the first epilogue, bias+residual in the second --
-and one LayerNorm launch."""
+MI355X: two MFMA GEMM launches -- bias+GELU in the first epilogue, bias+dropout+residual in the
+second -- and one LayerNorm launch."""
 from __future__ import annotations
 
 from typing import Union
@@ -37,8 +37,6 @@ class FeedForward(nn.Module):
 
     def forward(self, hidden_state: torch.Tensor, input_tensor: torch.Tensor) -> torch.Tensor:
         from ..autograd import ffn_block
-        from .attention import _check_dropout
-        _check_dropout(self, self.dropout.p)
         return ffn_block(hidden_state, input_tensor, self.intermediate.weight, self.intermediate.bias,
                          self.out.weight, self.out.bias, self.layernorm.weight, self.layernorm.bias,
-                         self.layernorm.eps, self.act)
+                         self.layernorm.eps, self.act, self.dropout.p, self.training)

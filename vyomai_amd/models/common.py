@@ -42,13 +42,30 @@ class LMHead(nn.Module):
         return ops.linear(x, _shadow(self.decoder.weight, dt), _shadow(self.bias, dt))
 
 
-    def loss(self, hidden_state: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    def loss(self, hidden_state: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100,
+             check_labels: bool = False) -> torch.Tensor:
         """Shifted CLM cross-entropy fused with the head (no fp32 logits copy): the training-side
-        entry point; see autograd_train.LMHeadLossFn."""
+        entry point; see autograd_train.LMHeadLossFn.  A label that is neither `ignore_index` nor a
+        vocabulary id (torch.cross_entropy device-asserts on it) is never dereferenced: its row counts as
+        ignored and the device flag `self.label_error` is raised -- `check_labels=True` (or
+        `raise_on_label_error()` whenever convenient: it synchronises) turns that into a ValueError."""
         from ..autograd_train import LMHeadLossFn
-        return LMHeadLossFn.apply(hidden_state, labels, ignore_index, self.dense.weight, self.dense.bias,
-                                  self.layer_norm.weight, self.layer_norm.bias, self.decoder.weight, self.bias,
-                                  self.layer_norm.eps)
+        flag = getattr(self, "label_error", None)
+        if flag is None or flag.device != hidden_state.device:
+            flag = self.label_error = torch.zeros(1, dtype=torch.int32, device=hidden_state.device)
+        out = LMHeadLossFn.apply(hidden_state, labels, ignore_index, self.dense.weight, self.dense.bias,
+                                 self.layer_norm.weight, self.layer_norm.bias, self.decoder.weight, self.bias,
+                                 self.layer_norm.eps, flag)
+        if check_labels:
+            self.raise_on_label_error()
+        return out
+
+    def raise_on_label_error(self) -> None:
+        flag = getattr(self, "label_error", None)
+        if flag is not None and int(flag.item()) != 0:
+            flag.zero_()
+            raise ValueError(f"labels contain ids outside [0, {self.decoder.weight.shape[0]}) other than "
+                             "ignore_index (those rows were treated as ignored)")
 
 
 class PositionMixin:

@@ -48,8 +48,9 @@ def _rows(x: Tensor) -> Tensor:
 
 def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = _lib.ACT_NONE,
            residual: Optional[Tensor] = None, pre_out: Optional[Tensor] = None,
-           out: Optional[Tensor] = None) -> Tensor:
-    """act(x @ w.T + bias) + residual   (vy_linear_fwd)."""
+           out: Optional[Tensor] = None, dropout: Optional[Tuple[float, int, int]] = None) -> Tensor:
+    """act(x @ w.T + bias) + residual   (vy_linear_fwd).
+    dropout = (p, seed, offset): dropout(x @ w.T + bias) / (1 - p) + residual  (vy_linear_dropout_fwd)."""
     _need_gpu(x, w, bias, residual)
     x2 = _rows(x)
     M, K = x2.shape
@@ -68,6 +69,12 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = _lib.
     p2 = _rows(pre_out) if pre_out is not None else None
     if p2 is not None:
         assert p2.stride(0) == y2.stride(0)
+    if dropout is not None and dropout[0] > 0.0:
+        assert act == _lib.ACT_NONE and p2 is None
+        call("vy_linear_dropout_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
+             _ptr(r2), r2.stride(0) if r2 is not None else 0, y2.data_ptr(), y2.stride(0), M, N, K,
+             float(dropout[0]), int(dropout[1]), int(dropout[2]), dtype_code(x.dtype), _stream())
+        return ret
     call("vy_linear_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
          _ptr(r2), r2.stride(0) if r2 is not None else 0, y2.data_ptr(), y2.stride(0), _ptr(p2),
          M, N, K, act, dtype_code(x.dtype), _stream())
@@ -284,10 +291,38 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, causal: bool, start_po
 
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tensor], lr: float,
                beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
-               grad_scale: float = 1.0) -> None:
-    _need_gpu(p, g, m, v, p_bf16)
+               grad_scale: float = 1.0, scale_dev: Optional[Tensor] = None) -> None:
+    """scale_dev: optional fp32 device scalar multiplied into grad_scale by the kernel (clip coefficient)."""
+    _need_gpu(p, g, m, v, p_bf16, scale_dev)
+    assert scale_dev is None or (scale_dev.dtype == torch.float32 and scale_dev.numel() == 1)
     call("vy_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), p.numel(),
-         lr, beta1, beta2, eps, weight_decay, step, grad_scale, _stream())
+         lr, beta1, beta2, eps, weight_decay, step, grad_scale, _ptr(scale_dev), _stream())
+
+
+def sumsq(x: Tensor) -> Tensor:
+    """sum(x^2) of a contiguous fp32 tensor as a device scalar (vy_sumsq; deterministic)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    call("vy_sumsq", x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), _stream())
+    return out[0]
+
+
+def dropout(x: Tensor, p: float, seed: int, offset: int, out: Optional[Tensor] = None) -> Tensor:
+    """x * keep(seed, offset, row, column) / (1 - p) over the (rows, last dim) view of x (vy_dropout): the
+    mask vy_linear_dropout_fwd applied in its epilogue for the same (seed, offset)."""
+    _need_gpu(x, out)
+    x2 = _rows(x)
+    if out is None:
+        out = torch.empty_like(x2)
+        ret = out.view(x.shape)
+    else:
+        ret = out
+    o2 = _rows(out)
+    call("vy_dropout", x2.data_ptr(), x2.stride(0), o2.data_ptr(), o2.stride(0), x2.shape[0], x2.shape[1],
+         float(p), int(seed), int(offset), dtype_code(x.dtype), _stream())
+    return ret
 
 
 def transpose(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
@@ -346,12 +381,14 @@ def act_bwd(dy: Tensor, pre: Tensor, act: int) -> Tensor:
     return out.view(pre.shape)
 
 
-def xent_fwd(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, loss_sum: Tensor, count: Tensor) -> None:
-    """logits2d: (M, V) view with 16-byte aligned, padded rows; labels int64 (M,)."""
-    _need_gpu(logits2d, labels, lse, loss_sum, count)
+def xent_fwd(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, loss_sum: Tensor, count: Tensor,
+             err_flag: Optional[Tensor] = None) -> None:
+    """logits2d: (M, V) view with 16-byte aligned, padded rows; labels int64 (M,).  err_flag: device int32,
+    set to 1 when a label is neither ignore_index nor in [0, V) (such rows count as ignored)."""
+    _need_gpu(logits2d, labels, lse, loss_sum, count, err_flag)
     M, V = logits2d.shape
     call("vy_xent_fwd", logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), ignore_index, lse.data_ptr(),
-         loss_sum.data_ptr(), count.data_ptr(), M, V, dtype_code(logits2d.dtype), _stream())
+         loss_sum.data_ptr(), count.data_ptr(), M, V, _ptr(err_flag), dtype_code(logits2d.dtype), _stream())
 
 
 def xent_bwd_(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, gscale: Tensor, count: Tensor) -> None:
@@ -421,13 +458,14 @@ def embedding_bwd_(dout: Tensor, ids: Tensor, dw: Tensor, padding_idx: Optional[
 
 
 def xent_fused_(logits2d: Tensor, labels: Tensor, ignore_index: int, lse: Tensor, loss_sum: Tensor,
-                count: Tensor, gscale: Tensor) -> None:
+                count: Tensor, gscale: Tensor, err_flag: Optional[Tensor] = None) -> None:
     """One pass: lse / loss_sum as xent_fwd, then logits <- d loss / d logits in place (vy_xent_fused).
     count (#rows with label != ignore) is an input here."""
-    _need_gpu(logits2d, labels, lse, loss_sum, count, gscale)
+    _need_gpu(logits2d, labels, lse, loss_sum, count, gscale, err_flag)
     M, V = logits2d.shape
     call("vy_xent_fused", logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), ignore_index, lse.data_ptr(),
-         loss_sum.data_ptr(), count.data_ptr(), gscale.data_ptr(), M, V, dtype_code(logits2d.dtype), _stream())
+         loss_sum.data_ptr(), count.data_ptr(), gscale.data_ptr(), M, V, _ptr(err_flag), dtype_code(logits2d.dtype),
+         _stream())
 
 
 def rmsnorm(x: Tensor, w: Tensor, eps: float, w_offset: float = 1.0) -> Tensor:

@@ -100,7 +100,7 @@ class FlatArena:
             self.shadow.copy_(self.master)
         if install:
             for p, o in zip(self.params, self.offsets):
-                p._vy_shadow = (p._version, self.shadow[o:o + p.numel()].view(p.shape))
+                p._vy_shadow = (p._version, self.shadow[o:o + p.numel()].view(p.shape), True)
 
     def _install_packed(self, model: nn.Module) -> None:
         """Point each attention module's packed weight/bias (and their bf16 shadows) at the arena."""
@@ -115,32 +115,44 @@ class FlatArena:
             o = index[id(ws[0])]
             assert all(w.numel() % ALIGN == 0 for w in ws)
             mod._packed_w = self.master[o:o + n_rows * k].view(n_rows, k)
+            sw = sb = None
             if self.shadow is not None:
-                mod._packed_w._vy_shadow = (mod._packed_w._version, self.shadow[o:o + n_rows * k].view(n_rows, k))
+                sw = self.shadow[o:o + n_rows * k].view(n_rows, k)
             if mod.attention_bias:
                 bs = [mod.query.bias, mod.key.bias, mod.value.bias]
                 assert all(b.numel() % ALIGN == 0 for b in bs)
                 ob = index[id(bs[0])]
                 mod._packed_b = self.master[ob:ob + n_rows]
                 if self.shadow is not None:
-                    mod._packed_b._vy_shadow = (mod._packed_b._version, self.shadow[ob:ob + n_rows])
+                    sb = self.shadow[ob:ob + n_rows]
             else:
                 mod._packed_b = None
+            if self.shadow is not None:
+                # keyed on the member versions, pinned to the arena (layers.attention._packed_shadow)
+                mod._vy_pshadow = (tuple(p._version for p in mod._params()), sw, sb, mod._packed_w.data_ptr(), True)
 
     def zero_grad(self) -> None:
         self.grad.zero_()
 
 
 class BucketReducer:
-    """Bucketed, overlapped gradient all-reduce over a flat gradient arena."""
+    """Bucketed, overlapped gradient all-reduce over a flat gradient arena.
+
+    comm_dtype: None reduces the fp32 arena in place (652 MB per step for the 12-layer decoder);
+    torch.bfloat16 reduces a bf16 copy of each bucket (326 MB) and writes the sum back in fp32 --
+    a ring all-reduce over xGMI is bound by ONE ~153 GB/s link, so halving the bytes halves the
+    exchange."""
 
     def __init__(self, arena: FlatArena, process_group=None, bucket_bytes: int = 64 << 20,
-                 average: bool = True):
+                 average: bool = True, comm_dtype: Optional[torch.dtype] = None):
         self.arena = arena
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
-        # buckets over the arena in REVERSE order: backward reaches the last layers first
+        self.comm_dtype = comm_dtype
+        self.enabled = True   # False during the non-final micro-steps of gradient accumulation
+        # buckets over the arena in REVERSE order: backward reaches the last layers first.  Only
+        # parameters that require gradients are waited for; a frozen one never reports.
         self.buckets: List[Tuple[int, int]] = []      # (start, end) element ranges
         self.bucket_of: Dict[int, int] = {}
         self.expect: List[int] = []
@@ -153,7 +165,8 @@ class BucketReducer:
             o = arena.offsets[idx]
             cur_start = o
             members.append(idx)
-            count += 1
+            if arena.params[idx].requires_grad:
+                count += 1
             if end - cur_start >= cap or idx == 0:
                 b = len(self.buckets)
                 self.buckets.append((cur_start, end))
@@ -161,18 +174,16 @@ class BucketReducer:
                 for m in members:
                     self.bucket_of[id(arena.params[m])] = b
                 end, count, members = cur_start, 0, []
-        self._pending = [0] * len(self.buckets)
-        self._launched = [False] * len(self.buckets)
-        self._works: List = []
-        self.launch_order: List[int] = []
-        self._seen: set = set()
+        self._comm: Dict[int, torch.Tensor] = {}
+        self.on_bucket = None
+        self.reset()
         # called as on_bucket(b, work) when bucket b's gradients are final on this rank and its
         # all-reduce (work, None when world == 1) has been enqueued -- the trainer steps the bucket
-        self.on_bucket = None
         for p in arena.params:
             p._vy_ready = self.mark_ready
-            # gradients produced by torch autograd itself (embedding tables) arrive through the tape
-            p.register_post_accumulate_grad_hook(self._hook)
+            if p.requires_grad:
+                # gradients produced by torch autograd itself (embedding tables) arrive through the tape
+                p.register_post_accumulate_grad_hook(self._hook)
 
     def _hook(self, p) -> None:
         # (a weight whose gradient launch has been deferred -- autograd_train._WgradGroup -- reports itself
@@ -183,11 +194,17 @@ class BucketReducer:
     def reset(self) -> None:
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
-        self._works = []
-        self.launch_order = []
-        self._seen = set()
+        self._works: List = []
+        self.launch_order: List[int] = []
+        self._seen: set = set()
+        self.touched: set = set()    # ids of the parameters that received a gradient since reset()
+        self.dirty = False
 
     def mark_ready(self, p) -> None:
+        self.touched.add(id(p))
+        if not self.enabled:
+            return
+        self.dirty = True
         b = self.bucket_of[id(p)]
         if self._launched[b]:
             return
@@ -207,10 +224,23 @@ class BucketReducer:
         if self.world > 1:
             s, e = self.buckets[b]
             view = self.arena.grad[s:e]
+            if self.comm_dtype is not None:
+                buf = self._comm.get(b)
+                if buf is None:
+                    buf = self._comm[b] = torch.empty(e - s, dtype=self.comm_dtype, device=view.device)
+                _convert(view, buf)
+                view = buf
             work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._works.append(work)
+            self._works.append((b, work))
         if self.on_bucket is not None:
             self.on_bucket(b, work)
+
+    def writeback(self, b: int) -> None:
+        """comm_dtype buckets: the reduced low-precision sum back into the fp32 arena (the caller has
+        made the current stream wait for the bucket's all-reduce)."""
+        if self.comm_dtype is not None and self.world > 1 and b in self._comm:
+            s, e = self.buckets[b]
+            _convert(self._comm[b], self.arena.grad[s:e])
 
     def finish(self) -> float:
         """Flush buckets whose parameters never got a gradient, wait for the exchange and return
@@ -218,18 +248,44 @@ class BucketReducer:
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
-        for w in self._works:
+        for b, w in self._works:
             w.wait()
+            if self.on_bucket is None:   # (an on_bucket consumer writes back on its own stream)
+                self.writeback(b)
         self._works = []
         return (1.0 / self.world) if (self.average and self.world > 1) else 1.0
 
 
+def _convert(src: torch.Tensor, dst: torch.Tensor) -> None:
+    if src.is_cuda:
+        from . import ops
+        ops.cast(src, dst)
+    else:
+        dst.copy_(src)
+
+
 class FlatTrainer:
-    """AdamW data-parallel trainer: bf16 HIP kernels, fp32 master weights, fused optimizer."""
+    """AdamW data-parallel trainer: bf16 HIP kernels, fp32 master weights, fused optimizer.
+
+    Mirrors what the reference's loops get from accelerate (Examples/vyom-ai-decoder_clm.ipynb cell 31:
+    Accelerator(gradient_accumulation_steps=2); Examples/vyomai-fused-kernals-2t4.ipynb cell 0:
+    clip_grad_norm_):
+      accumulate_steps  k > 1: backward() scales the loss by 1/k, gradients of k micro-steps add up in
+                        the arena, the buckets are reduced (and stepped) during the LAST micro-step's
+                        backward only; zero_grad() / optimizer_step() are no-ops in between, as under
+                        `with accelerator.accumulate(model)`.
+      max_grad_norm     global L2 clip over the reduced gradient arena (torch.nn.utils.clip_grad_norm_
+                        semantics: coefficient min(1, max_norm / (norm + 1e-6))) folded into the AdamW
+                        kernel's gradient scale on the device -- needs every gradient before the first
+                        update, so the per-bucket overlapped optimizer is off when it is set.
+    Parameters with requires_grad=False, and parameters that received no gradient in a step, are not
+    updated at all (torch.optim.AdamW skips p.grad is None: no weight decay either)."""
 
     def __init__(self, model: nn.Module, lr: float = 5e-5, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 0.01, compute_dtype: torch.dtype = torch.bfloat16,
-                 process_group=None, bucket_bytes: int = 64 << 20, overlap_optimizer: bool = True):
+                 process_group=None, bucket_bytes: int = 64 << 20, overlap_optimizer: bool = True,
+                 accumulate_steps: int = 1, max_grad_norm: Optional[float] = None,
+                 grad_comm_dtype: Optional[torch.dtype] = None):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         for m in model.modules():
@@ -238,47 +294,81 @@ class FlatTrainer:
         self.arena = FlatArena(model, shadow_dtype=compute_dtype)
         self.m = torch.zeros_like(self.arena.master)
         self.v = torch.zeros_like(self.arena.master)
-        self.reducer = BucketReducer(self.arena, process_group, bucket_bytes)
+        self.reducer = BucketReducer(self.arena, process_group, bucket_bytes, comm_dtype=grad_comm_dtype)
         self.step_count = 0
+        self.accumulate_steps = max(1, int(accumulate_steps))
+        self.max_grad_norm = max_grad_norm
+        self.last_grad_norm: Optional[torch.Tensor] = None   # device scalar (pre-clip norm of the last step)
+        self._micro = 0            # micro-steps taken since the last optimizer step
         # AdamW is an HBM stream (30 B/param), the backward GEMMs are not HBM-bound: each gradient
         # bucket is stepped on a side stream as soon as it is final (and reduced), under the rest of
         # backward.  A bucket is final only when every layer that owns a parameter in it has finished
         # its backward, so nothing that still runs reads the weights being rewritten.
         if os.environ.get("VY_OVERLAP_OPT") == "0":   # A/B knob
             overlap_optimizer = False
+        if max_grad_norm is not None:
+            overlap_optimizer = False
         self._side = torch.cuda.Stream() if (overlap_optimizer and self.arena.master.is_cuda) else None
         self._stepped: set = set()
         self._scale = (1.0 / self.reducer.world) if (self.reducer.average and self.reducer.world > 1) else 1.0
         if self._side is not None:
             self.reducer.on_bucket = self._bucket_final
+        self._needs_zero = False   # an optimizer step has consumed the arena: zero_grad() must come next
+
+    # ---- arena ranges that an update may touch ---------------------------------------------------
+    def _ranges(self, lo: int, hi: int, touched_only: bool) -> List[Tuple[int, int]]:
+        """Merged element ranges inside [lo, hi) of the parameters that are trainable (and, when
+        touched_only, received a gradient since zero_grad())."""
+        a = self.arena
+        out: List[Tuple[int, int]] = []
+        import bisect
+        i = bisect.bisect_right(a.offsets, lo) - 1
+        i = max(i, 0)
+        while i < len(a.params) and a.offsets[i] < hi:
+            p, o = a.params[i], a.offsets[i]
+            e = a.offsets[i + 1] if i + 1 < len(a.params) else a.numel
+            if o >= lo and p.requires_grad and (not touched_only or id(p) in self.reducer.touched):
+                if out and out[-1][1] == o:
+                    out[-1] = (out[-1][0], e)
+                else:
+                    out.append((o, e))
+            i += 1
+        return out
 
     def zero_grad(self) -> None:
+        if self._micro != 0:       # in the middle of an accumulation window: keep adding
+            return
         from .autograd_train import _wgrad_group
         _wgrad_group.discard()   # (only an aborted backward can have left deferred weight gradients behind)
         self.arena.zero_grad()
         self.reducer.reset()
         self._stepped = set()
-        self._backward_calls = 0
+        self._needs_zero = False
 
     def backward(self, loss: torch.Tensor) -> None:
-        if self.reducer.world > 1 and getattr(self, "_backward_calls", 0) >= 1:
-            # a bucket is all-reduced as soon as its gradients are final, i.e. during the first backward pass
-            raise RuntimeError("gradient accumulation over several backward passes is not supported with more than "
-                               "one rank (the buckets are reduced during the first pass)")
-        if self._side is not None and getattr(self, "_backward_calls", 0) >= 1:
-            # the per-bucket AdamW of the overlapped optimizer runs as soon as a bucket's gradients are final,
-            # i.e. during the FIRST backward pass after zero_grad()
-            raise RuntimeError("gradient accumulation over several backward passes needs "
-                               "FlatTrainer(..., overlap_optimizer=False)")
-        self._backward_calls = getattr(self, "_backward_calls", 0) + 1
-        loss.backward()
+        if self._needs_zero:
+            # the reducer still holds the previous step's state: every bucket counts as launched and
+            # stepped, so this backward would neither reduce nor update anything -- silently
+            raise RuntimeError("FlatTrainer.backward() after optimizer_step() without zero_grad(): call "
+                               "zero_grad() (or use train_step()) so the gradient arena and the bucket "
+                               "reducer start from a clean state")
+        k = self.accumulate_steps
+        last = (self._micro + 1) >= k
+        # buckets are reduced -- and, with the overlapped optimizer, stepped -- as soon as their gradients
+        # are final, which is only true in the last micro-step's backward
+        self.reducer.enabled = last
+        if last:
+            self.reducer._seen = set()
+        self._micro += 1
+        (loss / k if k > 1 else loss).backward()
+        self.reducer.enabled = True
 
-    def _adamw(self, lo: int, hi: int, step: int) -> None:
+    def _adamw(self, lo: int, hi: int, step: int, scale_dev: Optional[torch.Tensor] = None) -> None:
         from . import ops
         a = self.arena
         ops.adamw_step(a.master[lo:hi], a.grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
                        None if a.shadow is None else a.shadow[lo:hi], self.lr, self.betas[0], self.betas[1],
-                       self.eps, self.weight_decay, step, self._scale)
+                       self.eps, self.weight_decay, step, self._scale, scale_dev=scale_dev)
 
     def _bucket_final(self, b: int, work) -> None:
         """Reducer callback (during backward): step bucket b on the side stream."""
@@ -288,28 +378,84 @@ class FlatTrainer:
         with torch.cuda.stream(self._side):
             if work is not None:
                 work.wait()                                # the side stream waits for the all-reduce
-            self._adamw(lo, hi, self.step_count + 1)
+                self.reducer.writeback(b)
+            for s, e in self._ranges(lo, hi, touched_only=True):
+                self._adamw(s, e, self.step_count + 1)
         self._stepped.add(b)
 
-    def optimizer_step(self) -> None:
+    def _sumsq(self) -> torch.Tensor:
+        from . import ops
+        return ops.sumsq(self.arena.grad)
+
+    def grad_norm(self) -> torch.Tensor:
+        """L2 norm of the (averaged) gradient arena as a device scalar (after the exchange)."""
+        return self._sumsq().sqrt() * self._scale
+
+    def optimizer_step(self) -> bool:
+        """-> True when an update was applied (False inside an accumulation window)."""
         from .autograd_train import WEIGHT_EPOCH
 
+        if self._micro < self.accumulate_steps:
+            return False
+        self._micro = 0
         scale = self.reducer.finish()   # flushes buckets without gradients (their callbacks run here too)
         assert abs(scale - self._scale) < 1e-12
         self.step_count += 1
         if self._side is None:
-            self._adamw(0, self.arena.numel, self.step_count)
+            scale_dev = None
+            if self.max_grad_norm is not None:
+                # clip coefficient on the device: min(1, max_norm / (norm + 1e-6)); no host sync
+                norm = self._sumsq().sqrt() * self._scale
+                self.last_grad_norm = norm
+                scale_dev = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0).to(torch.float32).reshape(1)
+            for s, e in self._ranges(0, self.arena.numel, touched_only=True):
+                self._adamw(s, e, self.step_count, scale_dev)
         else:
             for b, (lo, hi) in enumerate(self.reducer.buckets):
                 if b not in self._stepped:
-                    self._adamw(lo, hi, self.step_count)
+                    for s, e in self._ranges(lo, hi, touched_only=True):
+                        self._adamw(s, e, self.step_count)
             torch.cuda.current_stream().wait_stream(self._side)
         WEIGHT_EPOCH[0] += 1
+        self._needs_zero = True
+        return True
 
     def train_step(self, loss_fn: Callable[[], torch.Tensor]) -> torch.Tensor:
-        """zero_grad -> loss_fn() -> backward (overlapped all-reduce) -> fused AdamW."""
+        """zero_grad -> loss_fn() -> backward (overlapped all-reduce) -> fused AdamW.  With
+        accumulate_steps = k this is ONE micro-step; the update happens on every k-th call."""
         self.zero_grad()
         loss = loss_fn()
         self.backward(loss)
         self.optimizer_step()
         return loss.detach()
+
+    # ---- checkpoint / external writes -----------------------------------------------------------
+    def resync(self, reset_moments: bool = False) -> None:
+        """After anything but this trainer wrote the parameters in place (load_state_dict, a manual
+        re-initialisation): recast the fp32 masters into the compute-dtype arena the kernels read and
+        invalidate every cached W^T."""
+        from .autograd_train import WEIGHT_EPOCH
+        self.arena.refresh_shadow(install=True)
+        self.arena._install_packed(self.model)
+        if reset_moments:
+            self.m.zero_()
+            self.v.zero_()
+            self.step_count = 0
+        WEIGHT_EPOCH[0] += 1
+
+    def load_state_dict(self, state_dict, strict: bool = True, reset_moments: bool = False):
+        """model.load_state_dict() into the master arena (the parameters are views of it), then resync()."""
+        out = self.model.load_state_dict(state_dict, strict=strict)
+        self.resync(reset_moments=reset_moments)
+        return out
+
+    def optimizer_state_dict(self) -> dict:
+        return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone(),
+                "names": [n for n, _ in self.arena.items], "offsets": list(self.arena.offsets)}
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        if list(sd["offsets"]) != list(self.arena.offsets):
+            raise ValueError("optimizer state was saved for a different parameter layout")
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_count = int(sd["step"])
