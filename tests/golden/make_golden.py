@@ -238,6 +238,59 @@ def gradients():
 
 
 # ---------------------------------------------------------------------------
+# D2. configs[3] training: reference autograd through (i) a one-layer Vit (patchify conv, cls token, the
+#     in-place double position add, VisionAttention with the fused qkv Linear at L = 197, FeedForward) and
+#     (ii) a VisionLanguageModel (1-layer Vit + 1-layer decoder, the image vector prepended as token 0) under
+#     the captioning notebooks' loss cross_entropy(logits[:, 1:-1], ids[:, 1:])
+#     (Examples/vyom-ai-accelerate-multimodel-2t4.ipynb cell 1).  eval() mode: dropout is the identity.
+# ---------------------------------------------------------------------------
+
+
+def _grad_sample(g: torch.Tensor):
+    g = g.detach()
+    if g.numel() <= 4096:
+        return g
+    g2 = g.reshape(g.shape[0], -1) if g.dim() != 3 else g.reshape(-1, g.shape[-1])
+    return cases.sub2(g2)
+
+
+def vision_gradients():
+    out = {}
+    torch.set_grad_enabled(True)
+    vcfg = cases.vit_cfg()
+    vcfg.num_hidden_layers = 1
+    img = T(recipe.uniform("vgrad.img", (2, 3, 224, 224), 0.5, 0.5))
+    vit = filled(Vit(vcfg), "vgrad.vit.")
+    y = vit(img.clone()).logits
+    g = T(recipe.uniform("vgrad.gout", tuple(y.shape)))
+    (y * g).sum().backward()
+    out["vit.y"] = cases.sub(y)
+    for n, p in vit.named_parameters():
+        out["vit.d." + n] = _grad_sample(p.grad)
+
+    for pos, at in (("rope", None), ("absolute", "gqa")):
+        c = cases.with_kv(cases.test_cfg(), at)
+        c.num_hidden_layers, c.vocab_size = 1, 1031
+        vlm = VisionLanguageModel(c, Vit(vcfg), pos, at)
+        filled(vlm, f"vgrad.vlm.{pos}.{at}.")
+        ids = T(recipe.token_ids("vgrad.ids", (2, 12), 3, c.vocab_size))
+        am = torch.ones(2, 12, dtype=torch.long)
+        am[1, 9:] = 0
+        logits = vlm(pixel_values=img.clone(), decoder_input_ids=ids, decoder_attention_mask=am).logits
+        tgt = ids[:, 1:].clone()
+        tgt[am[:, 1:] == 0] = -100
+        loss = torch.nn.functional.cross_entropy(logits[:, 1:-1].reshape(-1, logits.shape[-1]), tgt.reshape(-1),
+                                                 ignore_index=-100)
+        loss.backward()
+        out[f"vlm.{pos}.{at}.loss"] = loss.detach().reshape(1)
+        for n, p in vlm.named_parameters():
+            if p.grad is not None:
+                out[f"vlm.{pos}.{at}.d." + n] = _grad_sample(p.grad)
+    torch.set_grad_enabled(False)
+    save("grads_vision", **out)
+
+
+# ---------------------------------------------------------------------------
 # F. seq2seq: EncoderDecoderModel (cross-attention), forward + greedy generation in the three cache
 #    modes + gradients of one Seq2SeqDecoderLayer.  The reference tests' own inputs
 #    (tests/test_encoder_decoder.py:48-68).
@@ -396,13 +449,15 @@ def sampling():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["modules", "models", "grads", "paligemma", "seq2seq", "sampling"]
+    which = sys.argv[1:] or ["modules", "models", "grads", "vgrads", "paligemma", "seq2seq", "sampling"]
     if "modules" in which:
         module_level()
     if "models" in which:
         model_level()
     if "grads" in which:
         gradients()
+    if "vgrads" in which:
+        vision_gradients()
     if "paligemma" in which:
         paligemma_blocks()
     if "seq2seq" in which:

@@ -105,6 +105,10 @@ BWD_CASES = [
     (2, 4, 2, 130, 130, True, 0, True),
     (2, 3, 1, 70, 70, False, 0, True),
     (2, 12, 12, 512, 512, True, 0, False),
+    # ViT-B/16: 197 tokens, non-causal (VisionAttention, reference layers/attention.py:591-624)
+    (3, 12, 12, 197, 197, False, 0, False),
+    # odd length, non-causal, key padding (encoder attention under a padding mask)
+    (2, 12, 4, 131, 131, False, 0, True),
 ]
 
 

@@ -323,3 +323,129 @@ def test_vlm_caption_loss_matches_cross_entropy_of_the_logits():
     got_m = vlm.caption_loss(img, ids, am)
     assert abs(float(got_m) - float(want_m)) < 2e-2 * max(1.0, float(want_m)), (float(got_m), float(want_m))
     got_m.backward()
+
+
+# ---- configs[3] training: ViT and vision-language gradients vs the REAL reference's autograd -------------
+
+def _grad_sample(g):
+    g = g.detach().float().cpu()
+    if g.numel() <= 4096:
+        return g.numpy()
+    g2 = g.reshape(g.shape[0], -1) if g.dim() != 3 else g.reshape(-1, g.shape[-1])
+    return cases.sub2(g2).numpy()
+
+
+def _rel(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+
+
+def test_vit_gradients_vs_reference(golden):
+    """One-layer Vit, B = 2: patchify weight / bias, cls_token, position table (the in-place double add gives
+    both a factor 2), the fused qkv projection at L = 197 non-causal, FeedForward -- against the reference's
+    autograd (tests/golden/grads_vision.npz)."""
+    import vyomai_amd as V
+    g = golden("grads_vision")
+    vcfg = cases.vit_cfg()
+    vcfg.num_hidden_layers, vcfg.hidden_dropout_prob = 1, 0.0
+    vit = V.Vit(vcfg)
+    for n, t in vit.state_dict().items():
+        t.copy_(T(recipe.param_value("vgrad.vit." + n, tuple(t.shape))))
+    vit = vit.to(DEV).train()
+    img = T(recipe.uniform("vgrad.img", (2, 3, 224, 224), 0.5, 0.5)).to(DEV).to(BF)
+    y = vit(img).logits
+    gout = T(recipe.uniform("vgrad.gout", tuple(y.shape))).to(DEV)
+    (y.float() * gout).sum().backward()
+    assert _rel(cases.sub(y.detach().float().cpu()).numpy(), g["vit.y"]) < 3e-2
+    for n, p in vit.named_parameters():
+        assert p.grad is not None, f"{n} received no gradient"
+        e = _rel(_grad_sample(p.grad), g["vit.d." + n])
+        assert e < 6e-2, (n, e)
+
+
+@pytest.mark.parametrize("pos,at", [("rope", None), ("absolute", "gqa")])
+def test_vlm_caption_gradients_vs_reference(golden, pos, at):
+    """VisionLanguageModel (1-layer Vit + 1-layer decoder), caption loss with a padded row: the loss and every
+    gradient -- the encoder's included, which reach it only through the prepended image token -- against the
+    reference's autograd under cross_entropy(logits[:, 1:-1], ids[:, 1:])."""
+    import vyomai_amd as V
+    g = golden("grads_vision")
+    vcfg = cases.vit_cfg()
+    vcfg.num_hidden_layers, vcfg.hidden_dropout_prob = 1, 0.0
+    c = cases.with_kv(cases.test_cfg(), at)
+    c.num_hidden_layers, c.vocab_size, c.hidden_dropout_prob = 1, 1031, 0.0
+    vlm = V.VisionLanguageModel(c, V.Vit(vcfg), pos, at)
+    for n, t in vlm.state_dict().items():
+        if t.is_floating_point():
+            t.copy_(T(recipe.param_value(f"vgrad.vlm.{pos}.{at}." + n, tuple(t.shape))))
+    vlm = vlm.to(DEV).train()
+    for m in vlm.modules():
+        if hasattr(m, "compute_dtype"):
+            m.compute_dtype = BF
+    img = T(recipe.uniform("vgrad.img", (2, 3, 224, 224), 0.5, 0.5)).to(DEV).to(BF)
+    ids = T(recipe.token_ids("vgrad.ids", (2, 12), 3, c.vocab_size)).to(DEV)
+    am = torch.ones(2, 12, dtype=torch.long, device=DEV)
+    am[1, 9:] = 0
+    loss = vlm.caption_loss(img, ids, am)
+    loss.backward()
+    want = float(g[f"vlm.{pos}.{at}.loss"][0])
+    assert abs(float(loss) - want) < 2e-2 * max(1.0, want), (float(loss), want)
+    seen = 0
+    for n, p in vlm.named_parameters():
+        key = f"vlm.{pos}.{at}.d." + n
+        if key not in g:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, f"{n} received no gradient"
+        e = _rel(_grad_sample(p.grad), g[key])
+        assert e < 8e-2, (n, e)
+        seen += 1
+    assert seen > 20 and any(n.startswith("encoder.") for n, _ in vlm.named_parameters())
+
+
+def test_decoder_layer_at_the_benchmark_size_vs_oracle():
+    """One DecoderLayer at the size bench.py runs (B = 32, L = 512, d = 768, 12 heads, RoPE, causal), bf16 forward
+    AND backward, against fp32 autograd through the CPU oracle on the same recipe weights: the only kernels-vs-
+    oracle evidence at M = 16384 rows (the GEMM tiles, the flash attention grids and the grouped weight
+    gradients all take their large-shape paths here)."""
+    from vyomai_amd.layers.mask import AttnMask
+    from vyomai_amd.layers.positional_embeddings import RopeSlice, RopeTable
+    from vyomai_amd.models.decoder import DecoderLayer
+    import vyomai_amd as V
+    cfg = V.EncoderConfig(num_hidden_layers=1, max_position_embeddings=1024, hidden_dropout_prob=0.0)
+    B, L, d = 32, 512, cfg.hidden_size
+    dh = d // cfg.num_attention_heads
+    layer = DecoderLayer(cfg, 0, None)
+    for n, t in layer.state_dict().items():
+        t.copy_(T(recipe.param_value("big.layer." + n, tuple(t.shape))))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    layer = layer.to(DEV).train()
+    x0 = T(recipe.uniform("big.x", (B, L, d))).to(BF)
+    g0 = T(recipe.uniform("big.gout", (B, L, d))).to(BF)
+    x = x0.to(DEV).requires_grad_(True)
+    tab = O.rotary_angles(dh, cfg.max_position_embeddings)
+    mask = AttnMask.from_padding(None, causal=True, start_pos=0, query_len=L)
+    y, _ = layer(x, mask, RopeSlice(RopeTable(tab), 0, L))
+    (y.float() * g0.to(DEV).float()).sum().backward()
+    torch.cuda.synchronize()
+    # oracle: fp32, all host cores
+    xr = x0.float().requires_grad_(True)
+    c = O.Cfg.of(cfg)
+    add = O.decoder_additive_mask(B, L, None, 0, torch.float32)
+    yr = O.block(sd, "", c, xr, add, tab[:, :L], False)
+    (yr * g0.float()).sum().backward()
+
+    def rel(a, b):
+        return float((a.detach().float().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-12))
+
+    def rel_rms(a, b):
+        a, b = a.detach().float().cpu(), b.detach()
+        return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12))
+    assert rel(y, yr) < 3e-2, rel(y, yr)
+    assert rel_rms(y, yr) < 6e-3, rel_rms(y, yr)
+    assert rel(x.grad, xr.grad) < 6e-2, rel(x.grad, xr.grad)
+    assert rel_rms(x.grad, xr.grad) < 1.5e-2, rel_rms(x.grad, xr.grad)
+    for n, p in layer.named_parameters():
+        e = rel(p.grad, sd[n].grad)
+        assert e < 6e-2, (n, e)

@@ -245,6 +245,35 @@ class EmbeddingFn(torch.autograd.Function):
         return None, dw.to(w.dtype), None, None
 
 
+class PatchifyFn(torch.autograd.Function):
+    """tokens = patches W^T + b with W the stride == kernel Conv2d weight (d, C, p, p) viewed (d, C*p*p): the
+    ViT patch embedding (reference models/vision_encoder.py:83-88, 114).  Backward is the weight / bias
+    gradient only -- the pixels are data."""
+
+    @staticmethod
+    def forward(ctx, patches, w, b):
+        _require_bf16(patches)
+        dt = patches.dtype
+        ctx.save_for_backward(patches)
+        ctx.params = (w, b)
+        return ops.linear(patches, _shadow(w, dt).reshape(w.shape[0], -1), _shadow(b, dt))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        w, b = ctx.params
+        dy = dy.contiguous()
+        N = w.shape[0]
+        if _direct(w) and (b is None or _direct(b)):
+            ops.linear_wgrad(dy, patches, w.grad.view(N, -1), None if b is None else b.grad, accumulate=True)
+            _notify(w, b)
+            return None, None, None
+        dw = torch.empty((N, w.numel() // N), dtype=torch.float32, device=w.device)
+        db = torch.empty(b.shape, dtype=torch.float32, device=w.device) if b is not None else None
+        ops.linear_wgrad(dy, patches, dw, db, accumulate=False)
+        return None, dw.view(w.shape).to(w.dtype), (db.to(b.dtype) if b is not None else None)
+
+
 class LinearResidualLayerNormFn(torch.autograd.Function):
     """y = LN(x W^T + b + residual).  AttentionSelfOutput (reference layers/attention.py:69-72)."""
 

@@ -63,6 +63,9 @@ class Vit(nn.Module):
         x = pixel_values.reshape(b, c, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(b, gh * gw, c * ph * pw)
         w = self.pixel_seq.weight
         dt = pixel_values.dtype
+        if torch.is_grad_enabled() and w.requires_grad:
+            from ..autograd_train import PatchifyFn
+            return PatchifyFn.apply(x.contiguous(), w, self.pixel_seq.bias)
         w2 = _shadow(w, dt).reshape(w.shape[0], -1)
         return ops.linear(x.contiguous(), w2, _shadow(self.pixel_seq.bias, dt))
 
