@@ -1358,6 +1358,198 @@ __global__ __launch_bounds__(256) void splitk_finish_ln_kernel(const float* __re
   }
 }
 
+// ---- the same GEMM, its combine AND the LayerNorm in ONE launch (decode) -------------------------
+// A decode step is a chain of short dependent kernels, each of which costs ~4 us before it has done
+// anything (launch, first memory round trip, drain): the split-K GEMM + its finish kernel were 4.9 +
+// 6.3 us for 1.2-4.7 MB of weights.  Here the workgroup that is LAST to deliver a K-slice of a 32-column
+// tile adds that tile's partials (+ bias, activation, residual), and the workgroup that is last to
+// finish a TILE normalises the rows -- two levels of "last arriver", no workgroup ever waits for
+// another (no spin, no residency assumption, any dispatch order or XCD placement).  Hand-off per level
+// (cdna_hip_programming.md, Guideline 16 / split-K combine): plain stores -> every storing wave's
+// s_waitcnt vmcnt(0) -> workgroup barrier -> one lane's agent-scope release fence + vmcnt(0) -> relaxed
+// agent-scope ticket add; the drawer of the last ticket does an agent-scope acquire + vmcnt(0) +
+// barrier and reads with plain vector loads.  The last finisher zeroes the tickets for the next launch
+// (the workspace starts zeroed).  Arithmetic order = gemm_skinny_splitk_kernel + splitk_finish_ln_kernel
+// (partials added in slice order, + bias, activation, + residual, rounded to bf16, then the LayerNorm
+// of layernorm_fwd_kernel): bit-identical to the two-launch path.
+template <int ACT>
+__global__ __launch_bounds__(256) void gemm_skinny_splitk_ln_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N, int K,
+    int steps_per_wg, float* __restrict__ part, bf16* __restrict__ srow, unsigned* __restrict__ tickets,
+    const bf16* __restrict__ bias, const bf16* __restrict__ residual, int64_t ldr,
+    const bf16* __restrict__ gamma, const bf16* __restrict__ beta, bf16* __restrict__ y, int64_t ldy, float eps) {
+  __shared__ float red[3][16][64];
+  __shared__ unsigned drawn;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nb = blockIdx.x, ks = blockIdx.y, ksplit = gridDim.y, ntile = gridDim.x;
+  const int col = nb * 32 + fr;
+  const int mr = fr < M ? fr : M - 1;
+  const bf16* wp = W + (int64_t)col * ldw + fh * 8;
+  const bf16* xp = X + (int64_t)mr * ldx + fh * 8;
+  const int nsteps = K >> 4;
+  const int s_end = min(nsteps, (ks + 1) * steps_per_wg);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int s = ks * steps_per_wg + wave;
+  for (; s + 20 < s_end; s += 24) {
+    bf16x8 a[6], b[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      a[u] = *reinterpret_cast<const bf16x8*>(wp + 16 * (s + 4 * u));
+      b[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 4 * u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; s + 4 < s_end; s += 8) {
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      a[u] = *reinterpret_cast<const bf16x8*>(wp + 16 * (s + 4 * u));
+      b[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 4 * u));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  for (; s < s_end; s += 4) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(wp + 16 * s);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    if (fr < M) {
+      float* dst = part + ((int64_t)ks * 32 + fr) * N + nb * 32 + 4 * fh;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 v = {acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]};
+        *reinterpret_cast<f32x4*>(dst + 8 * rg) = v;
+      }
+    }
+    // level 1: this K-slice of tile nb is delivered (only wave 0 stored)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      drawn = __hip_atomic_fetch_add(tickets + 1 + nb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (drawn != (unsigned)(ksplit - 1)) return;          // workgroup-uniform
+  // ---- last deliverer of tile nb: combine its K-slices ------------------------------------------
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 3, c4 = (tid & 7) * 4;       // 32 rows x 8 quads
+    if (row < M) {
+      const int n = nb * 32 + c4;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x4 pk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        pk[k] = *reinterpret_cast<const f32x4*>(part + ((int64_t)(k < ksplit ? k : 0) * 32 + row) * N + n);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k < ksplit) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] += pk[k][e];
+        }
+      }
+      if (bias) {
+        const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += (float)b4[e];
+      }
+      if constexpr (ACT != VY_ACT_NONE) {
+        // as the skinny kernel's epilogue (epi_plain_quad): the activation of the fp32 sum
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = vy_act_fwd<ACT>(a[e]);
+      }
+      if (residual) {
+        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(residual + (int64_t)row * ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += (float)r4[e];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)a[e];
+      *reinterpret_cast<bf16x4*>(srow + (int64_t)row * N + n) = o;
+    }
+  }
+  // level 2: tile nb of the pre-LayerNorm rows is delivered (every wave stored)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (drawn != (unsigned)(ntile - 1)) return;
+  // ---- last tile: LayerNorm of the M rows (one wave per row, as layernorm_fwd_kernel) -----------
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (tid <= ntile)   // tickets back to zero for the next launch (nobody else touches them any more)
+    __hip_atomic_store(tickets + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int nch = N / 8;
+  for (int row = wave; row < M; row += 4) {
+    constexpr int CH = 16;                                  // N <= 8192
+    float v[CH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(srow + (int64_t)row * N + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; sum += v[c][e]; }
+      }
+    }
+    const float mean = vy_wave_sum(sum) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+      }
+    }
+    const float var = vy_wave_sum(q) / (float)N;
+    const float rstd = rsqrtf(var + eps);
+    const float rstd_r = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nch) {
+        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gamma + ch * 8);
+        const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(beta + ch * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[c][e] - mean) * rstd_r * (float)g8[e] + (float)b8[e]);
+        *reinterpret_cast<bf16x8*>(y + (int64_t)row * ldy + ch * 8) = o;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // f32 MFMA kernel (parity path): 64x64 tile, BK=16, 4 waves of 32x32, mfma_f32_32x32x2f32
 // ------------------------------------------------------------------------------------------
@@ -1766,7 +1958,8 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
 // internal: vy_qkv_rope_fwd with the token position read from device memory (graph replay)
 // y = LN(x W^T + bias + residual) for M <= 32 rows (decode), bf16: split-K GEMM + fused finish.
 // `part` is an fp32 scratch of vy_splitk_ws_floats(N) elements.  Internal to the decode driver.
-int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N; }
+// partials (8 slices x 32 rows x N fp32) + the pre-LayerNorm rows (32 x N bf16) + 256 tickets
+int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N + 16 * N + 256; }
 
 extern "C" int vy_debug_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 
@@ -1776,13 +1969,18 @@ extern "C" int vy_debug_gemm_clock(unsigned long long* out3) {   // out3: 6 valu
   if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(vy_gemm_clk), sizeof(z)) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(vy_gemm_clk), z, sizeof(z)) != hipSuccess;
 }
+// fused = 1: ONE launch (gemm_skinny_splitk_ln_kernel); `part` must then be followed by the row buffer and the
+// tickets (vy_splitk_ws_floats covers all three) and start zeroed.  act: activation before the residual add
+// (the LM head's dense + GELU + LayerNorm); the two-launch path has no activation.
 int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                             const void* residual, int64_t ldr, const void* gamma, const void* beta, float eps,
-                            void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream) {
+                            void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream,
+                            int fused, int act) {
   const char* who = "vy_linear_res_ln_skinny";
   if (!x || !w || !gamma || !beta || !y || !part) VY_FAIL(VY_ERR_ARG, "%s: null operand", who);
   if (M < 1 || M > 32 || N % 32 || K % 16 || N > 8192) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: needs M <= 32, N %% 32 == 0 (<= 8192), K %% 16 == 0", who);
   if (ldx % 8 || ldw % 8 || ldy % 8 || (residual && ldr % 8)) VY_FAIL(VY_ERR_ARG, "%s: strides must be multiples of 8", who);
+  if (act != VY_ACT_NONE && !fused) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: an activation needs the fused path", who);
   hipStream_t st = (hipStream_t)stream;
   const int nsteps = (int)(K / 16), nwg = (int)(N / 32);
   int ksplit = (256 + nwg - 1) / nwg;            // ~one workgroup per CU
@@ -1792,6 +1990,23 @@ int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t l
   int spw = (nsteps + ksplit - 1) / ksplit;
   spw = (spw + 3) / 4 * 4;
   ksplit = (nsteps + spw - 1) / spw;
+  if (fused) {
+    if (nwg > 255) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: fused path needs N <= 8160", who);
+    bf16* srow = (bf16*)(part + 8 * 32 * N);
+    unsigned* tickets = (unsigned*)(srow + 32 * N);
+#define FUSED_GO(ACT_)                                                                                             \
+    hipLaunchKernelGGL((gemm_skinny_splitk_ln_kernel<ACT_>), dim3((unsigned)nwg, (unsigned)ksplit), dim3(256), 0, st, \
+                       (const bf16*)x, ldx, (const bf16*)w, ldw, (int)M, (int)N, (int)K, spw, part, srow, tickets,    \
+                       (const bf16*)bias, (const bf16*)residual, ldr, (const bf16*)gamma, (const bf16*)beta,          \
+                       (bf16*)y, ldy, eps)
+    if (act == VY_ACT_NONE) FUSED_GO(VY_ACT_NONE);
+    else if (act == VY_ACT_GELU_ERF) FUSED_GO(VY_ACT_GELU_ERF);
+    else if (act == VY_ACT_GELU_TANH) FUSED_GO(VY_ACT_GELU_TANH);
+    else VY_FAIL(VY_ERR_ARG, "%s: unknown activation %d", who, act);
+#undef FUSED_GO
+    VY_CHECK_LAUNCH(who);
+    return VY_OK;
+  }
   hipLaunchKernelGGL(gemm_skinny_splitk_kernel, dim3((unsigned)nwg, (unsigned)ksplit), dim3(256), 0, st, (const bf16*)x,
                      ldx, (const bf16*)w, ldw, (int)M, (int)N, (int)K, spw, part);
   VY_CHECK_LAUNCH(who);

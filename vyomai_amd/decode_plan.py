@@ -93,7 +93,7 @@ class DecodePlan:
         plan.head_ln_w, plan.head_ln_b = sh(head.layer_norm.weight), sh(head.layer_norm.bias)
         plan.head_wv, plan.head_bias = sh(head.decoder.weight), sh(head.bias)
         nbytes = lib.vy_decode_ws_bytes(batch, d, h, hk, dh, ffn, plan.dtype)
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # (the fused kernels' tickets start at 0)
         plan.ws, plan.ws_bytes = self.ws.data_ptr(), nbytes
         self.plan = plan
         self.batch, self.d, self.vocab, self.dtype, self.device = batch, d, cfg.vocab_size, dtype, device
