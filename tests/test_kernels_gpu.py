@@ -236,56 +236,3 @@ def test_rope_standalone_and_inverse(dtype):
     # two roundings per direction in bf16: allow 3 ulps
     check(back, x, 1e-2 if dtype == torch.bfloat16 else 1e-6, 1.2e-2 if dtype == torch.bfloat16 else 0,
           "rope inverse round trip")
-
-
-@pytest.mark.parametrize("M,N,K,act,res", [(32, 768, 768, 0, True), (32, 768, 3072, 0, True), (5, 768, 768, 1, False),
-                                           (17, 2048, 1024, 0, True), (1, 256, 256, 0, False)])
-def test_decode_projection_layernorm_one_launch(M, N, K, act, res):
-    """The decode step's split-K projection + bias / activation / residual + LayerNorm as ONE launch (two levels of
-    last-arriver hand-offs between workgroups) against the two-launch form, bit for bit, launch after launch --
-    a stale read in a hand-off shows up as a mismatch in some launch -- and against fp64."""
-    import ctypes as C
-    ops, _lib = _ops()
-    lib = _lib.load()
-    f = lib.vy_debug_linear_res_ln_skinny
-    f.restype = C.c_int
-    f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
-                  C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_int]
-    lib.vy_debug_splitk_ws_floats.restype = C.c_int64
-    lib.vy_debug_splitk_ws_floats.argtypes = [C.c_int64]
-    bf = torch.bfloat16
-    w = rnd(N, K, seed=2, scale=1 / math.sqrt(K)).to(bf).to(DEV)
-    b = rnd(N, seed=3, scale=0.1).to(bf).to(DEV)
-    gam = (1 + rnd(N, seed=5, scale=0.1)).to(bf).to(DEV)
-    bet = rnd(N, seed=6, scale=0.1).to(bf).to(DEV)
-    ws = torch.zeros(lib.vy_debug_splitk_ws_floats(N), dtype=torch.float32, device=DEV)
-    ws2 = torch.zeros_like(ws)
-    st = torch.cuda.current_stream().cuda_stream
-    junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
-    rounds = 40 if act == 0 else 10
-    for it in range(rounds):
-        x = rnd(M, K, seed=10 + it).to(bf).to(DEV)
-        r = rnd(M, N, seed=100 + it).to(bf).to(DEV) if res else None
-        y1 = torch.empty(M, N, dtype=bf, device=DEV)
-        rp = r.data_ptr() if res else None
-        if it % 3 == 0:
-            junk.random_(0, 255)   # other traffic in flight / caches disturbed: uneven arrival order
-        rc = f(x.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), rp, N, gam.data_ptr(), bet.data_ptr(), 1e-5,
-               y1.data_ptr(), N, ws.data_ptr(), M, N, K, st, 1, act)
-        assert rc == 0, lib.vy_last_error()
-        if act == 0:
-            y0 = torch.empty(M, N, dtype=bf, device=DEV)
-            rc = f(x.data_ptr(), K, w.data_ptr(), K, b.data_ptr(), rp, N, gam.data_ptr(), bet.data_ptr(), 1e-5,
-                   y0.data_ptr(), N, ws2.data_ptr(), M, N, K, st, 0, 0)
-            assert rc == 0, lib.vy_last_error()
-            assert torch.equal(y0, y1), f"launch {it}: fused and two-launch results differ"
-        pre = x.double() @ w.double().t() + b.double()
-        pre = ACTS[act](pre)
-        if res:
-            pre = pre + r.double()
-        want = torch.nn.functional.layer_norm(pre.to(bf).double(), (N,), gam.double(), bet.double(), 1e-5)
-        check(y1, want, 6e-2, 2e-2, f"fused projection + LN {M}x{N}x{K} launch {it}")
-    torch.cuda.synchronize()
-    # the tickets are back at zero after every launch
-    tickets = ws.view(torch.int32)[8 * 32 * N + 16 * N:]
-    assert int(tickets.abs().sum()) == 0

@@ -436,28 +436,61 @@ __global__ __launch_bounds__(64 * NWV) void attn_rowwise_kernel(AttnParams p, in
   float m = -FLT_MAX, l = 0.f, acc[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
-  // U key groups per trip: their K and V chunks are all requested before the first dot product,
-  // so a wave keeps 2*U 16-byte loads in flight (decode is a pure HBM stream of the KV cache)
+  // U key groups per trip: their K and V chunks are all requested before the first dot product, AND the
+  // next trip's are requested before this trip's arithmetic (raw 16-byte registers, converted at use): a
+  // wave keeps up to 4*U 16-byte loads in flight, so the dependent trips of a row overlap instead of each
+  // paying a memory latency (decode is a pure HBM stream of the KV cache; S = 577 is 5 trips)
   constexpr int U = 4;
-  for (int j0 = wave * KPP; j0 < S_eff; j0 += NWV * KPP * U) {
-    float kv[U][VEC], vv[U][VEC], t[U];
-    bool valid[U];
-    int jc[U];
+  constexpr int STRIDE = NWV * KPP * U;
+  typedef f32x4 raw16;
+  auto key_of = [&](int j0, int u, bool& valid) {
+    const int j = j0 + u * NWV * KPP + grp;
+    valid = j < S_eff;
+    return valid ? j : S_eff - 1;
+  };
+  auto request = [&](int j0, raw16 (&kr)[U], raw16 (&vr)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int j = j0 + u * NWV * KPP + grp;
-      valid[u] = j < S_eff;
-      jc[u] = valid[u] ? j : S_eff - 1;
-      RowVec<T>::load(Kb + (int64_t)jc[u] * p.k_sl + chl * VEC, kv[u]);
+      bool ok;
+      const int jc = key_of(j0, u, ok);
+      kr[u] = *reinterpret_cast<const raw16*>(Kb + (int64_t)jc * p.k_sl + chl * VEC);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) RowVec<T>::load(Vb + (int64_t)jc[u] * p.v_sl + chl * VEC, vv[u]);
+    for (int u = 0; u < U; ++u) {
+      bool ok;
+      const int jc = key_of(j0, u, ok);
+      vr[u] = *reinterpret_cast<const raw16*>(Vb + (int64_t)jc * p.v_sl + chl * VEC);
+    }
+  };
+  auto widen = [&](const raw16& r, float (&o)[VEC]) {
+    if constexpr (VEC == 8) {
+      const bf16x8 t = __builtin_bit_cast(bf16x8, r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (float)t[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = r[e];
+    }
+  };
+  raw16 kcur[U], vcur[U];
+  int j0 = wave * KPP;
+  if (j0 < S_eff) request(j0, kcur, vcur);
+  for (; j0 < S_eff; j0 += STRIDE) {
+    raw16 knext[U], vnext[U];
+    const bool more = j0 + STRIDE < S_eff;   // wave-uniform
+    if (more) request(j0 + STRIDE, knext, vnext);
+    float t[U];
+    bool valid[U];
+    int jc[U];
     float mn = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      jc[u] = key_of(j0, u, valid[u]);
+      float kv[VEC];
+      widen(kcur[u], kv);
       float d = 0.f;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) d = fmaf(qv[e], kv[u][e], d);
+      for (int e = 0; e < VEC; ++e) d = fmaf(qv[e], kv[e], d);
 #pragma unroll
       for (int o_ = CPR >> 1; o_ > 0; o_ >>= 1) d += __shfl_xor(d, o_, 64);
       float x = d * p.scale;
@@ -476,10 +509,16 @@ __global__ __launch_bounds__(64 * NWV) void attn_rowwise_kernel(AttnParams p, in
     for (int u = 0; u < U; ++u) {
       const float e_ = valid[u] ? __expf(t[u] - mn) : 0.f;
       l += e_;
+      float vv[VEC];
+      widen(vcur[u], vv);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[e] = fmaf(e_, vv[u][e], acc[e]);
+      for (int e = 0; e < VEC; ++e) acc[e] = fmaf(e_, vv[e], acc[e]);
     }
     m = mn;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) { kcur[u] = knext[u]; vcur[u] = vnext[u]; }
+    }
   }
   // combine the KPP key groups of the wave (lanes with equal ch), then the 4 waves through LDS
 #pragma unroll

@@ -1358,193 +1358,231 @@ __global__ __launch_bounds__(256) void splitk_finish_ln_kernel(const float* __re
   }
 }
 
-// ---- the same GEMM, its combine AND the LayerNorm in ONE launch (decode) -------------------------
-// A decode step is a chain of short dependent kernels, each of which costs ~4 us before it has done
-// anything (launch, first memory round trip, drain): the split-K GEMM + its finish kernel were 4.9 +
-// 6.3 us for 1.2-4.7 MB of weights.  Here the workgroup that is LAST to deliver a K-slice of a 32-column
-// tile adds that tile's partials (+ bias, activation, residual), and the workgroup that is last to
-// finish a TILE normalises the rows -- two levels of "last arriver", no workgroup ever waits for
-// another (no spin, no residency assumption, any dispatch order or XCD placement).  Hand-off per level
-// (cdna_hip_programming.md, Guideline 16 / split-K combine): plain stores -> every storing wave's
-// s_waitcnt vmcnt(0) -> workgroup barrier -> one lane's agent-scope release fence + vmcnt(0) -> relaxed
-// agent-scope ticket add; the drawer of the last ticket does an agent-scope acquire + vmcnt(0) +
-// barrier and reads with plain vector loads.  The last finisher zeroes the tickets for the next launch
-// (the workspace starts zeroed).  Arithmetic order = gemm_skinny_splitk_kernel + splitk_finish_ln_kernel
-// (partials added in slice order, + bias, activation, + residual, rounded to bf16, then the LayerNorm
-// of layernorm_fwd_kernel): bit-identical to the two-launch path.
-template <int ACT>
-__global__ __launch_bounds__(256) void gemm_skinny_splitk_ln_kernel(
-    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N, int K,
-    int steps_per_wg, float* __restrict__ part, bf16* __restrict__ srow, unsigned* __restrict__ tickets,
-    const bf16* __restrict__ bias, const bf16* __restrict__ residual, int64_t ldr,
-    const bf16* __restrict__ gamma, const bf16* __restrict__ beta, bf16* __restrict__ y, int64_t ldy, float eps) {
-  __shared__ float red[3][16][64];
-  __shared__ unsigned drawn;
+// (A one-launch form of the split-K GEMM + combine + LayerNorm -- the workgroup that delivers the last K-slice
+// of a tile combines it, the one that finishes the last tile normalises the rows; sc1 write-through hand-offs,
+// no spinning -- was built, was bit-identical, and made the decode step 1.5x SLOWER (1.03 vs 0.69 ms): two
+// dependent cross-CU hand-offs inside a launch (drain write-through stores, ticket, sc1 loads from beyond L2)
+// cost ~15 us against ~1.7 us for a kernel boundary.  On this chip a chain of short dependent phases is
+// cheapest as launches in a graph, and each launch is made as short as possible instead.)
+
+// y = LayerNorm(bf16(sum_ks part[ks] + bias + residual)), ONE WORKGROUP PER ROW: every thread requests its
+// 4 columns of all partial tiles, bias, residual, gamma and beta at once (one memory round trip), then two
+// block reductions.  (splitk_finish_ln_kernel walks a row with one wave: 6.4 us per launch against ~2.5.)
+template <int QPT>
+__global__ __launch_bounds__(256) void splitk_finish_ln_row_kernel(const float* __restrict__ part, int ksplit, int M,
+                                                                   int N, const bf16* __restrict__ bias,
+                                                                   const bf16* __restrict__ residual, int64_t ldr,
+                                                                   const bf16* __restrict__ gamma,
+                                                                   const bf16* __restrict__ beta, bf16* __restrict__ y,
+                                                                   int64_t ldy, float eps) {
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x;
+  const int nq = N >> 2;
+  f32x4 pk[QPT][8];
+  bf16x4 b4[QPT], r4[QPT], g4[QPT], be4[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + 256 * i;
+    const int n = (q < nq ? q : 0) * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      pk[i][k] = *reinterpret_cast<const f32x4*>(part + ((int64_t)(k < ksplit ? k : 0) * 32 + row) * N + n);
+    if (bias) b4[i] = *reinterpret_cast<const bf16x4*>(bias + n);
+    if (residual) r4[i] = *reinterpret_cast<const bf16x4*>(residual + (int64_t)row * ldr + n);
+    g4[i] = *reinterpret_cast<const bf16x4*>(gamma + n);
+    be4[i] = *reinterpret_cast<const bf16x4*>(beta + n);
+  }
+  float v[QPT][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const bool ok = tid + 256 * i < nq;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < ksplit) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += pk[i][k][e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (bias) a[e] += (float)b4[i][e];
+      if (residual) a[e] += (float)r4[i][e];
+      v[i][e] = ok ? vy_round_bf16(a[e]) : 0.f;
+      s += v[i][e];
+    }
+  }
+  s = vy_wave_sum(s);
+  if (lane == 0) red[0][wave] = s;
+  __syncthreads();
+  const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)N;
+  float qv = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    if (tid + 256 * i < nq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; qv += d * d; }
+    }
+  }
+  qv = vy_wave_sum(qv);
+  if (lane == 0) red[1][wave] = qv;
+  __syncthreads();
+  const float var = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)N;
+  const float rstd = rsqrtf(var + eps);
+  const float rstd_r = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + 256 * i;
+    if (q < nq) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[i][e] - mean) * rstd_r * (float)g4[i][e] + (float)be4[i][e]);
+      *reinterpret_cast<bf16x4*>(y + (int64_t)row * ldy + q * 4) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 16 output columns per workgroup (M <= 32): the decode projections with N/32 < ~200 workgroups leave most
+// of the 256 CUs without a weight stream, and ONE CU pulls only ~25-40 GB/s (what its L1 keeps in flight
+// over a memory latency), so such a launch runs at a quarter of the chip's bandwidth.  Halving the tile
+// doubles the CUs that stream: mfma_f32_16x16x32_bf16, A = 16 weight rows x 32 k, B = 16 batch rows x 32 k
+// (two row blocks), K split over the workgroup's 4 waves, partial sums through LDS.  D[n][m]: a lane owns
+// batch row lane & 15 and the 4 consecutive columns 4 * (lane >> 4) .. + 3.  With fused RoPE a workgroup
+// takes columns {d0 .. d0+7} and {d0+32 .. d0+39} of one head: a rotary pair sits in lanes l and l ^ 32.
+// ------------------------------------------------------------------------------------------
+template <int EPI, int ACT>
+__global__ __launch_bounds__(256) void gemm_skinny16_bf16_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, EpiPlain<bf16> ep, EpiQkv<bf16> eq, int dbg) {
+  __shared__ float red[3][8][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fr = lane & 31, fh = lane >> 5;
-  const int nb = blockIdx.x, ks = blockIdx.y, ksplit = gridDim.y, ntile = gridDim.x;
-  const int col = nb * 32 + fr;
-  const int mr = fr < M ? fr : M - 1;
-  const bf16* wp = W + (int64_t)col * ldw + fh * 8;
-  const bf16* xp = X + (int64_t)mr * ldx + fh * 8;
-  const int nsteps = K >> 4;
-  const int s_end = min(nsteps, (ks + 1) * steps_per_wg);
-  f32x16 acc;
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int nb = blockIdx.x;
+  const bool rope_map = (EPI == 1) && eq.rope;
+  int col = nb * 16 + r16;
+  if (rope_map) col = (nb >> 2) * 64 + (nb & 3) * 8 + (r16 < 8 ? r16 : 24 + r16);
+  const int wr = col < N ? col : N - 1;
+  const int m0r = r16 < M ? r16 : M - 1, m1r = 16 + r16 < M ? 16 + r16 : M - 1;
+  const bf16* wp = W + (int64_t)wr * ldw + kq * 8;
+  const bf16* xp0 = X + (int64_t)m0r * ldx + kq * 8;
+  const bf16* xp1 = X + (int64_t)m1r * ldx + kq * 8;
+  // measurement knobs (VY_SKINNY_DBG; wrong results): 1 = every lane reads X row 0, 2 = every workgroup reads the
+  // weight rows of tile 0, 4 = one k-step only, 8 = no epilogue, 16 = return at once
+  if (dbg & 16) return;
+  if (dbg & 1) { xp0 = X + kq * 8; xp1 = xp0; }
+  if (dbg & 2) wp = W + (int64_t)r16 * ldw + kq * 8;
+  const bool two = M > 16;   // (wave-uniform) a second block of batch rows exists
+  // the epilogue's operands that do not depend on the product (bias, residual, rotary cos / sin) are requested
+  // up front, under the weight stream: loaded after the reduction they are one more dependent memory round
+  // trip in a kernel that is nothing but round trips (measured: the epilogue was 2 of this kernel's ~5 us)
+  const int nq0 = rope_map ? (nb >> 2) * 64 + (nb & 3) * 8 + 4 * (kq & 1) + (kq >= 2 ? 32 : 0) : nb * 16 + 4 * kq;
+  const bf16* biasp = EPI == 0 ? ep.bias : eq.bias;
+  const bool fast = nq0 + 3 < N && (EPI == 1 || ep.vec_ok);
+  bf16x4 bias4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  if (biasp && fast) bias4 = *reinterpret_cast<const bf16x4*>(biasp + nq0);
+  bf16x4 res4[2];
+  if (EPI == 0 && fast && ep.residual) {
+    res4[0] = *reinterpret_cast<const bf16x4*>(ep.residual + (int64_t)m0r * ep.ldr + nq0);
+    res4[1] = *reinterpret_cast<const bf16x4*>(ep.residual + (int64_t)m1r * ep.ldr + nq0);
+  }
+  f32x4 cos4[2], sin4[2];
+  if (rope_map) {
+    const int64_t pbase = eq.pos_dev ? (int64_t)*eq.pos_dev : eq.pos0;
+    const int dcol = (nb & 3) * 8 + 4 * (kq & 1);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  int s = ks * steps_per_wg + wave;
-  for (; s + 20 < s_end; s += 24) {
-    bf16x8 a[6], b[6];
+    for (int blk = 0; blk < 2; ++blk) {
+      const int64_t mm = blk == 0 ? m0r : m1r;
+      const int64_t pp = pbase + (mm - (mm / eq.L) * eq.L);
+      cos4[blk] = *reinterpret_cast<const f32x4*>(eq.cos_tab + pp * 32 + dcol);
+      sin4[blk] = *reinterpret_cast<const f32x4*>(eq.sin_tab + pp * 32 + dcol);
+    }
+  }
+  const int nsteps = (dbg & 4) ? 4 : K >> 5;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  int s = wave;
+  constexpr int U = 6;   // K = 768: the wave's 6 k-steps in one trip, 18 loads in flight per lane
+  for (; s + 4 * (U - 1) < nsteps; s += 4 * U) {
+    bf16x8 a[U], b0[U], b1[U];
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      a[u] = *reinterpret_cast<const bf16x8*>(wp + 16 * (s + 4 * u));
-      b[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 4 * u));
+    for (int u = 0; u < U; ++u) {
+      a[u] = *reinterpret_cast<const bf16x8*>(wp + 32 * (s + 4 * u));
+      b0[u] = *reinterpret_cast<const bf16x8*>(xp0 + 32 * (s + 4 * u));
+      b1[u] = *reinterpret_cast<const bf16x8*>(xp1 + 32 * (s + 4 * u));
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < 6; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
-  }
-  for (; s + 4 < s_end; s += 8) {
-    bf16x8 a[2], b[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      a[u] = *reinterpret_cast<const bf16x8*>(wp + 16 * (s + 4 * u));
-      b[u] = *reinterpret_cast<const bf16x8*>(xp + 16 * (s + 4 * u));
+    for (int u = 0; u < U; ++u) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b0[u], acc0, 0, 0, 0);
+      if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b1[u], acc1, 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
   }
-  for (; s < s_end; s += 4) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(wp + 16 * s);
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  for (; s < nsteps; s += 4) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(wp + 32 * s);
+    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(xp0 + 32 * s);
+    const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(xp1 + 32 * s);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc0, 0, 0, 0);
+    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc1, 0, 0, 0);
   }
   if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    for (int r = 0; r < 4; ++r) { red[wave - 1][r][lane] = acc0[r]; red[wave - 1][4 + r][lane] = acc1[r]; }
   }
   __syncthreads();
-  if (wave == 0) {
+  if (wave != 0) return;
+  if (dbg & 8) { if (acc0[0] == 12345.678f) ep.y[0] = (bf16)acc1[0]; return; }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
-    if (fr < M) {
-      float* dst = part + ((int64_t)ks * 32 + fr) * N + nb * 32 + 4 * fh;
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const f32x4 v = {acc[4 * rg], acc[4 * rg + 1], acc[4 * rg + 2], acc[4 * rg + 3]};
-        *reinterpret_cast<f32x4*>(dst + 8 * rg) = v;
-      }
-    }
-    // level 1: this K-slice of tile nb is delivered (only wave 0 stored)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      drawn = __hip_atomic_fetch_add(tickets + 1 + nb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  for (int r = 0; r < 4; ++r) {
+    acc0[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    acc1[r] += red[0][4 + r][lane] + red[1][4 + r][lane] + red[2][4 + r][lane];
   }
-  __syncthreads();
-  if (drawn != (unsigned)(ksplit - 1)) return;          // workgroup-uniform
-  // ---- last deliverer of tile nb: combine its K-slices ------------------------------------------
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  {
-    const int row = tid >> 3, c4 = (tid & 7) * 4;       // 32 rows x 8 quads
-    if (row < M) {
-      const int n = nb * 32 + c4;
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-      f32x4 pk[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        pk[k] = *reinterpret_cast<const f32x4*>(part + ((int64_t)(k < ksplit ? k : 0) * 32 + row) * N + n);
+  for (int blk = 0; blk < 2; ++blk) {
+    const int64_t m = blk * 16 + r16;
+    if (m >= M) continue;
+    float v[4];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (k < ksplit) {
+    for (int r = 0; r < 4; ++r) v[r] = blk == 0 ? acc0[r] : acc1[r];
+    if constexpr (EPI == 0) {
+      if (fast && !ep.pre && !ep.residual2 && !ep.drop.thr) {   // epi_plain_quad on the prefetched operands
 #pragma unroll
-          for (int e = 0; e < 4; ++e) a[e] += pk[k][e];
+        for (int i = 0; i < 4; ++i) v[i] = vy_act_fwd<ACT>(v[i] + (float)bias4[i]);
+        if (ep.residual) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += (float)res4[blk][i];
         }
+        Quad<bf16>::store(ep.y + m * ep.ldy + nq0, v);
+      } else {
+        epi_plain_quad<bf16, ACT, false>(ep, v, m, nb * 16 + 4 * kq, N);
       }
-      if (bias) {
-        const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n);
+    } else {
+      if (!rope_map) {
+        epi_qkv_quad<bf16>(eq, v, m, nb * 16 + 4 * kq, N);
+      } else {
+        // this lane: columns nq0 .. nq0+3 of the packed [q | k | v] row (the high half of the head for kq >= 2);
+        // the other half of each rotary pair is in lane ^ 32
+        const bool hi_half = kq >= 2;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] += (float)b4[e];
-      }
-      if constexpr (ACT != VY_ACT_NONE) {
-        // as the skinny kernel's epilogue (epi_plain_quad): the activation of the fp32 sum
+        for (int i = 0; i < 4; ++i) v[i] += (float)bias4[i];
+        float other[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = vy_act_fwd<ACT>(a[e]);
-      }
-      if (residual) {
-        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(residual + (int64_t)row * ldr + n);
+        for (int i = 0; i < 4; ++i) other[i] = __shfl_xor(v[i], 32, 64);
+        const int64_t b = m / eq.L, l = m - b * eq.L;
+        if (nq0 < eq.nq + eq.nkv) {
+          // reference op order (positional_embeddings.py:173-181), every product rounded to bf16: epi_qkv_pair
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] += (float)r4[e];
-      }
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)a[e];
-      *reinterpret_cast<bf16x4*>(srow + (int64_t)row * N + n) = o;
-    }
-  }
-  // level 2: tile nb of the pre-LayerNorm rows is delivered (every wave stored)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    drawn = __hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (drawn != (unsigned)(ntile - 1)) return;
-  // ---- last tile: LayerNorm of the M rows (one wave per row, as layernorm_fwd_kernel) -----------
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();
-  if (tid <= ntile)   // tickets back to zero for the next launch (nobody else touches them any more)
-    __hip_atomic_store(tickets + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int nch = N / 8;
-  for (int row = wave; row < M; row += 4) {
-    constexpr int CH = 16;                                  // N <= 8192
-    float v[CH][8];
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int ch = lane + 64 * c;
-      if (ch < nch) {
-        const bf16x8 t = *reinterpret_cast<const bf16x8*>(srow + (int64_t)row * N + ch * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; sum += v[c][e]; }
-      }
-    }
-    const float mean = vy_wave_sum(sum) / (float)N;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int ch = lane + 64 * c;
-      if (ch < nch) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
-      }
-    }
-    const float var = vy_wave_sum(q) / (float)N;
-    const float rstd = rsqrtf(var + eps);
-    const float rstd_r = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int ch = lane + 64 * c;
-      if (ch < nch) {
-        const bf16x8 g8 = *reinterpret_cast<const bf16x8*>(gamma + ch * 8);
-        const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(beta + ch * 8);
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)((v[c][e] - mean) * rstd_r * (float)g8[e] + (float)b8[e]);
-        *reinterpret_cast<bf16x8*>(y + (int64_t)row * ldy + ch * 8) = o;
+          for (int i = 0; i < 4; ++i) {
+            const float c = vy_round_bf16(cos4[blk][i]), sn = vy_round_bf16(sin4[blk][i]);
+            const float mine = vy_round_bf16(v[i]), oth = vy_round_bf16(other[i]);
+            // low half: a*c - b*s;  high half: b*c + a*s   (a = low element, b = high element)
+            v[i] = hi_half ? vy_round_bf16(mine * c) + vy_round_bf16(oth * sn)
+                           : vy_round_bf16(mine * c) - vy_round_bf16(oth * sn);
+          }
+        }
+        Quad<bf16>::store(qkv_dest(eq, b, l, nq0), v);
       }
     }
   }
@@ -1691,12 +1729,19 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
   static const int rot = [] { const char* e = getenv("VY_GEMM_ROT"); return e ? atoi(e) : 0; }();  // rotated k order: measured 1-5 % slower
   static const int mid_tiles = [] { const char* e = getenv("VY_GEMM_MID"); return e ? atoi(e) : 1; }();
   static const int gemv_on = [] { const char* e = getenv("VY_GEMV"); return e ? atoi(e) : 1; }();
+  static const int skinny16_on = [] { const char* e = getenv("VY_SKINNY16"); return e ? atoi(e) : 1; }();
   static const int64_t skinny_max_n = [] { const char* e = getenv("VY_SKINNY_MAXN"); return e ? (int64_t)atoll(e) : (int64_t)8192; }();   // wider (the vocabulary): 32 x 128 tiles with X staged once per workgroup -- 15.5 vs 31.1 us at N = 50265
   if (M <= 4 && (EPI == 0 || !eq.rope) && !GRAD && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && gemv_on &&
       ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0)) {
     if constexpr (!GRAD && (EPI == 1 ? ACT == 0 : true))
       hipLaunchKernelGGL((gemv_bf16_kernel<EPI, ACT, 4>), dim3((unsigned)vy_cdiv(N, 4)), dim3(256), 0, st, X, ldx, W, ldw,
                          (int)M, (int)N, (int)K, ep, eq);
+  } else if (M <= 32 && K % 32 == 0 && !GRAD && N % 16 == 0 && N / 32 < 200 && skinny16_on &&
+             (EPI == 0 || !eq.rope || (N % 64 == 0 && eq.dh == 64))) {
+    // few 32-column workgroups: 16-column ones, so that twice as many CUs stream weights
+    static const int sk_dbg = [] { const char* e = getenv("VY_SKINNY_DBG"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL((gemm_skinny16_bf16_kernel<EPI, ACT>), dim3((unsigned)(N / 16)), dim3(256), 0, st, X, ldx,
+                       W, ldw, (int)M, (int)N, (int)K, ep, eq, sk_dbg);
   } else if (M <= 32 && K % 16 == 0 && !GRAD && (EPI == 0 || !eq.rope || N % 64 == 0) && N <= skinny_max_n) {
     hipLaunchKernelGGL((gemm_skinny_bf16_kernel<EPI, ACT>), dim3((unsigned)vy_cdiv(N, 32)), dim3(256), 0, st, X, ldx,
                        W, ldw, (int)M, (int)N, (int)K, ep, eq);
@@ -1958,8 +2003,7 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
 // internal: vy_qkv_rope_fwd with the token position read from device memory (graph replay)
 // y = LN(x W^T + bias + residual) for M <= 32 rows (decode), bf16: split-K GEMM + fused finish.
 // `part` is an fp32 scratch of vy_splitk_ws_floats(N) elements.  Internal to the decode driver.
-// partials (8 slices x 32 rows x N fp32) + the pre-LayerNorm rows (32 x N bf16) + 256 tickets
-int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N + 16 * N + 256; }
+int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N; }
 
 extern "C" int vy_debug_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
 
@@ -1969,18 +2013,13 @@ extern "C" int vy_debug_gemm_clock(unsigned long long* out3) {   // out3: 6 valu
   if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(vy_gemm_clk), sizeof(z)) != hipSuccess) return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(vy_gemm_clk), z, sizeof(z)) != hipSuccess;
 }
-// fused = 1: ONE launch (gemm_skinny_splitk_ln_kernel); `part` must then be followed by the row buffer and the
-// tickets (vy_splitk_ws_floats covers all three) and start zeroed.  act: activation before the residual add
-// (the LM head's dense + GELU + LayerNorm); the two-launch path has no activation.
 int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                             const void* residual, int64_t ldr, const void* gamma, const void* beta, float eps,
-                            void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream,
-                            int fused, int act) {
+                            void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream) {
   const char* who = "vy_linear_res_ln_skinny";
   if (!x || !w || !gamma || !beta || !y || !part) VY_FAIL(VY_ERR_ARG, "%s: null operand", who);
   if (M < 1 || M > 32 || N % 32 || K % 16 || N > 8192) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: needs M <= 32, N %% 32 == 0 (<= 8192), K %% 16 == 0", who);
   if (ldx % 8 || ldw % 8 || ldy % 8 || (residual && ldr % 8)) VY_FAIL(VY_ERR_ARG, "%s: strides must be multiples of 8", who);
-  if (act != VY_ACT_NONE && !fused) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: an activation needs the fused path", who);
   hipStream_t st = (hipStream_t)stream;
   const int nsteps = (int)(K / 16), nwg = (int)(N / 32);
   int ksplit = (256 + nwg - 1) / nwg;            // ~one workgroup per CU
@@ -1990,26 +2029,23 @@ int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t l
   int spw = (nsteps + ksplit - 1) / ksplit;
   spw = (spw + 3) / 4 * 4;
   ksplit = (nsteps + spw - 1) / spw;
-  if (fused) {
-    if (nwg > 255) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: fused path needs N <= 8160", who);
-    bf16* srow = (bf16*)(part + 8 * 32 * N);
-    unsigned* tickets = (unsigned*)(srow + 32 * N);
-#define FUSED_GO(ACT_)                                                                                             \
-    hipLaunchKernelGGL((gemm_skinny_splitk_ln_kernel<ACT_>), dim3((unsigned)nwg, (unsigned)ksplit), dim3(256), 0, st, \
-                       (const bf16*)x, ldx, (const bf16*)w, ldw, (int)M, (int)N, (int)K, spw, part, srow, tickets,    \
-                       (const bf16*)bias, (const bf16*)residual, ldr, (const bf16*)gamma, (const bf16*)beta,          \
-                       (bf16*)y, ldy, eps)
-    if (act == VY_ACT_NONE) FUSED_GO(VY_ACT_NONE);
-    else if (act == VY_ACT_GELU_ERF) FUSED_GO(VY_ACT_GELU_ERF);
-    else if (act == VY_ACT_GELU_TANH) FUSED_GO(VY_ACT_GELU_TANH);
-    else VY_FAIL(VY_ERR_ARG, "%s: unknown activation %d", who, act);
-#undef FUSED_GO
-    VY_CHECK_LAUNCH(who);
-    return VY_OK;
-  }
   hipLaunchKernelGGL(gemm_skinny_splitk_kernel, dim3((unsigned)nwg, (unsigned)ksplit), dim3(256), 0, st, (const bf16*)x,
                      ldx, (const bf16*)w, ldw, (int)M, (int)N, (int)K, spw, part);
   VY_CHECK_LAUNCH(who);
+  static const int row_fin = [] { const char* e = getenv("VY_DECODE_ROW_FINISH"); return e ? atoi(e) : 1; }();
+  if (row_fin && N % 4 == 0) {   // one workgroup per row
+    const int qpt = (int)vy_cdiv(N / 4, 256);
+#define ROW_GO(Q)                                                                                               \
+    hipLaunchKernelGGL((splitk_finish_ln_row_kernel<Q>), dim3((unsigned)M), dim3(256), 0, st, part, ksplit, (int)M, (int)N, \
+                       (const bf16*)bias, (const bf16*)residual, ldr, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, ldy, eps)
+    if (qpt <= 1) ROW_GO(1);
+    else if (qpt <= 2) ROW_GO(2);
+    else if (qpt <= 4) ROW_GO(4);
+    else ROW_GO(8);
+#undef ROW_GO
+    VY_CHECK_LAUNCH(who);
+    return VY_OK;
+  }
   const int nch = (int)(N / 8);
   const dim3 grid((unsigned)((M + 3) / 4)), block(256);
 #define FIN_GO(CH)                                                                                               \

@@ -16,21 +16,7 @@ int vy_attn_decode_ex(const void* q, int64_t q_sb, int64_t q_sh, const void* k, 
 int64_t vy_splitk_ws_floats(int64_t N);
 int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
                             const void* residual, int64_t ldr, const void* gamma, const void* beta, float eps,
-                            void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream,
-                            int fused, int act);
-
-// -1: read VY_DECODE_FUSED at first use; vy_debug_set_decode_fused() switches it at run time (tests, A/B timing;
-// not part of include/vyom_hip.h)
-static int g_decode_fused = -1;
-extern "C" int vy_debug_set_decode_fused(int v) { g_decode_fused = v; return 0; }
-// the split-K projection + LayerNorm pair on its own (tests): see vy_linear_res_ln_skinny
-extern "C" int vy_debug_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias,
-                                             const void* residual, int64_t ldr, const void* gamma, const void* beta,
-                                             float eps, void* y, int64_t ldy, float* ws, int64_t M, int64_t N, int64_t K,
-                                             void* stream, int fused, int act) {
-  return vy_linear_res_ln_skinny(x, ldx, w, ldw, bias, residual, ldr, gamma, beta, eps, y, ldy, ws, M, N, K, stream, fused, act);
-}
-extern "C" int64_t vy_debug_splitk_ws_floats(int64_t N) { return vy_splitk_ws_floats(N); }
+                            void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream);
 
 namespace {
 inline int64_t esize(int dtype) { return dtype == VY_BF16 ? 2 : 4; }
@@ -66,9 +52,6 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
   // M <= 32 rows in bf16: the two N = d projections (24 workgroups as plain skinny GEMMs) run split-K
   // over ~all CUs, their bias + residual + LayerNorm fused into the kernel that adds the partials
   const bool splitk = p->dtype == VY_BF16 && B <= 32 && d % 32 == 0 && d <= 8192 && p->ffn % 16 == 0;
-  // GEMM + combine + LayerNorm in one launch (VY_DECODE_FUSED=0: the two-launch form, for A/B runs and tests)
-  if (g_decode_fused < 0) { const char* e = getenv("VY_DECODE_FUSED"); g_decode_fused = e ? atoi(e) : 1; }
-  const int fused = (g_decode_fused && d <= 8160) ? 1 : 0;
   const float scale = 1.0f / sqrtf((float)dh);
   const void* cur = x;
   for (int l = 0; l < p->num_layers; ++l) {
@@ -87,8 +70,7 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
                            L.c_sl, ao, d, B, h, hk, pos + 1, pos_dev, dh, scale, p->dtype, stream);
     if (rc) return rc;
     if (splitk) {
-      rc = vy_linear_res_ln_skinny(ao, d, L.wo, d, L.bo, cur, d, L.ln1_w, L.ln1_b, p->eps_attn, a, d, part, B, d, d, stream,
-                                   fused, VY_ACT_NONE);
+      rc = vy_linear_res_ln_skinny(ao, d, L.wo, d, L.bo, cur, d, L.ln1_w, L.ln1_b, p->eps_attn, a, d, part, B, d, d, stream);
       if (rc) return rc;
     } else {
       rc = vy_linear_fwd(ao, d, L.wo, d, L.bo, cur, d, s, d, nullptr, B, d, d, VY_ACT_NONE, p->dtype, stream);
@@ -102,7 +84,7 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
     void* nxt = hb[l & 1];
     if (splitk) {
       rc = vy_linear_res_ln_skinny(mid, p->ffn, L.w2, p->ffn, L.b2, cur, d, L.ln2_w, L.ln2_b, p->eps_ffn, nxt, d, part, B,
-                                   d, p->ffn, stream, fused, VY_ACT_NONE);
+                                   d, p->ffn, stream);
       if (rc) return rc;
     } else {
       rc = vy_linear_fwd(mid, p->ffn, L.w2, p->ffn, L.b2, cur, d, s, d, nullptr, B, d, p->ffn, VY_ACT_NONE, p->dtype, stream);
@@ -117,18 +99,11 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
       VY_FAIL(VY_ERR_LAUNCH, "%s: copy of the hidden state failed", who);
   }
   if (logits) {
-    int rc;
-    if (splitk && fused) {   // LMHead.dense + GELU + LayerNorm (reference models/decoder.py:267-273) in one launch
-      rc = vy_linear_res_ln_skinny(cur, d, p->head_wd, d, p->head_bd, nullptr, 0, p->head_ln_w, p->head_ln_b, p->eps_head,
-                                   a, d, part, B, d, d, stream, 1, VY_ACT_GELU_ERF);
-      if (rc) return rc;
-    } else {
-      rc = vy_linear_fwd(cur, d, p->head_wd, d, p->head_bd, nullptr, 0, s, d, nullptr, B, d, d, VY_ACT_GELU_ERF,
-                         p->dtype, stream);
-      if (rc) return rc;
-      rc = vy_layernorm_fwd(s, d, p->head_ln_w, p->head_ln_b, a, d, nullptr, nullptr, B, d, p->eps_head, p->dtype, stream);
-      if (rc) return rc;
-    }
+    int rc = vy_linear_fwd(cur, d, p->head_wd, d, p->head_bd, nullptr, 0, s, d, nullptr, B, d, d, VY_ACT_GELU_ERF,
+                           p->dtype, stream);
+    if (rc) return rc;
+    rc = vy_layernorm_fwd(s, d, p->head_ln_w, p->head_ln_b, a, d, nullptr, nullptr, B, d, p->eps_head, p->dtype, stream);
+    if (rc) return rc;
     rc = vy_linear_fwd(a, d, p->head_wv, d, p->head_bias, nullptr, 0, logits, ldv, nullptr, B, p->vocab, d,
                        VY_ACT_NONE, p->dtype, stream);
     if (rc) return rc;

@@ -64,10 +64,36 @@ __global__ __launch_bounds__(ST) void greedy_step_kernel(const T* __restrict__ l
   float best_v = -INFINITY;
   if (!forced) {   // block-uniform
     const T* row = logits + (int64_t)b * ldl;
-    for (int i = tid; i < V; i += ST) {
-      const float v = ldf(row, i);
+    auto take = [&](float v, int i) {
       if (v > best_v || (v == best_v && i < best_i) || best_i == 0x7fffffff) { best_v = v; best_i = i; }
+    };
+    int i0 = 0;
+    if constexpr (std::is_same<T, bf16>::value) {
+      // 16-byte chunks, all of a thread's chunks requested before the first compare (V = 50265: 7 per thread;
+      // one 2-byte load per trip made this kernel 24 us of dependent round trips)
+      if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+        const int nch = V >> 3;
+        constexpr int CPT = 8;
+        for (int c0 = 0; c0 < nch; c0 += ST * CPT) {
+          bf16x8 ch[CPT];
+#pragma unroll
+          for (int u = 0; u < CPT; ++u) {
+            const int c = c0 + u * ST + tid;
+            if (c < nch) ch[u] = *reinterpret_cast<const bf16x8*>(row + (int64_t)c * 8);
+          }
+#pragma unroll
+          for (int u = 0; u < CPT; ++u) {
+            const int c = c0 + u * ST + tid;
+            if (c < nch) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) take((float)ch[u][e], c * 8 + e);
+            }
+          }
+        }
+        i0 = nch << 3;
+      }
     }
+    for (int i = i0 + tid; i < V; i += ST) take(ldf(row, i), i);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(best_v, o, 64);
