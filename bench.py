@@ -124,24 +124,58 @@ def roofline_probe(cfg, B, L, dev):
     t_blk = event_time_us(block, 10, st)
     f_gemm = 24.0 * d * d * M
     f_blk = block_flops_per_token(d, L) * M
-    # HBM-side bytes per launch come from the committed PMC run (rocprofv3 cannot wrap this process
-    # from the inside): profiles/r01_gemm_pmc.json, same four launches, same shapes
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")) as f:
-            traffic = round(json.load(f)["avg_hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM-side bytes per launch come from a rocprofv3 --pmc run of the same four launches (rocprofv3 cannot wrap
+    # this process from the inside): tools/regen_profiles.sh writes profiles/rNN_gemm_pmc.json every round; the
+    # newest one is reported, with its name
+    traffic, traffic_file, alg_bytes = None, None, None
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_pmc.json")), reverse=True):
+        try:
+            with open(fn) as f:
+                j = json.load(f)
+            traffic = round(j["avg_hbm_bytes_per_launch"])
+            alg_bytes = round(j.get("algorithmic_bytes_per_launch", 0)) or None
+            traffic_file = os.path.relpath(fn, ROOT)
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     return {
         "bound": "mfma", "kernel": "gemm_nt_bf16_kernel (4 launches of one layer: qkv+rope, out+res, ffn1+gelu, ffn2+res)",
         "achieved": round(f_gemm / t_gemm * 1e-6, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(f_gemm / t_gemm * 1e-6 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-        "traffic_note": "HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), profiles/r01_gemm_pmc.json",
+        "traffic_note": f"HBM bytes/launch from rocprofv3 PMC (2*FETCH_SIZE+WRITE_SIZE), {traffic_file}; "
+                        f"algorithmic bytes/launch {alg_bytes}",
+        "measured_ceilings": measured_ceilings(dev),
         "avg_launch_us": round(t_gemm / 4, 1), "flops_per_launch": f_gemm / 4,
         "block_forward": {"us": round(t_blk, 1), "achieved": round(f_blk / t_blk * 1e-6, 1),
                           "frac": round(f_blk / t_blk * 1e-6 / PEAK_BF16_TFLOPS, 4),
                           "flops": f_blk, "convention": "24 d^2 + 2 S d per token (causal)"},
     }
+
+
+def measured_ceilings(dev):
+    """What this device delivers on the two bounding resources, measured in the same run next to the spec peaks
+    (SURVEY section 8d): the matrix pipe alone (six independent MFMA chains per wave, 8 waves per CU, non-trivial
+    operands, no memory traffic) and a plain 16-byte-per-lane copy of 1 GiB (read + write bytes counted)."""
+    import ctypes as C
+    from vyomai_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream()
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    wgs, iters = 256 * 4, 4000
+    lib.vy_debug_mfma_peak.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.vy_debug_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    t = event_time_us(lambda: lib.vy_debug_mfma_peak(wgs, iters, sink.data_ptr(), st.cuda_stream), 3, st)
+    mfma = wgs * 8 * iters * 6 * 2.0 * 32 * 32 * 16 / t * 1e-6
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.zero_()
+    t = event_time_us(lambda: lib.vy_debug_copy(a.data_ptr(), b.data_ptr(), n, st.cuda_stream), 5, st)
+    del a, b
+    return {"mfma_bf16_TFLOPs": round(mfma, 1), "mfma_spec_TFLOPs": PEAK_BF16_TFLOPS,
+            "hbm_copy_GBs": round(2.0 * n / t * 1e-3, 1), "hbm_spec_GBs": PEAK_HBM_GBS,
+            "note": "MFMA-only loop (6 chains x 8 waves per CU) and a 1 GiB copy (read + write bytes), this run"}
 
 
 def host_cores() -> int:
@@ -161,14 +195,16 @@ def host_cores() -> int:
 
 
 def cpu_baseline(cfg, seq):
-    """The oracle (CPU restatement of the reference) timed on the host: forward+backward of the
-    12-layer decoder on a bounded sample (B=2 x seq) -> training tokens/s on the CPU."""
+    """The oracle (CPU restatement of the reference, pinned to reference-made golden vectors) timed on the host
+    cores, the two legs SURVEY section 8d / BASELINE.md section 5 name: forward+backward of the 12-layer decoder at
+    B=4 x seq (training tokens/s) and a B=1 cached greedy decode of 32 tokens behind a 64-token prompt (decode
+    tokens/s).  Bounded: at most ~25 s of CPU work in all."""
     from oracle import vyom_oracle as O
-    from tests.golden import cases
     from vyomai_amd import recipe
+    from vyomai_amd.shapes import text_model_shapes
     nthreads = host_cores()
     torch.set_num_threads(nthreads)
-    shapes = cases.text_model_shapes(cfg, "rope", None, head=True)
+    shapes = text_model_shapes(cfg, "rope", None, head=True)
     sd = {}
     for n, s in shapes.items():
         if n.endswith("decoder.bias"):
@@ -176,7 +212,7 @@ def cpu_baseline(cfg, seq):
         sd[n] = torch.from_numpy(recipe.param_value(n, s)).requires_grad_(True)
     sd["lm_head.decoder.bias"] = sd["lm_head.bias"]
     c = O.Cfg.of(cfg)
-    B = 1
+    B = 4
     ids = torch.from_numpy(recipe.token_ids("bench.cpu", (B, seq), 3, cfg.vocab_size))
     t0 = time.time()
     n = 0
@@ -185,11 +221,29 @@ def cpu_baseline(cfg, seq):
         loss = O.clm_loss(out.logits, ids)
         loss.backward()
         n += 1
-        if time.time() - t0 > 10 or n >= 4:
+        if time.time() - t0 > 12 or n >= 3:
             break
     dt = time.time() - t0
+    # decode leg
+    with torch.no_grad():
+        sdn = {k: v.detach() for k, v in sd.items()}
+        prompt = ids[:1, :64]
+        new = 32
+        O.decoder_generate(sdn, c, prompt, torch.ones(1, 64), max_len=2, pos_type="rope", attn_type=None,
+                           use_cache=True, use_static_cache=True, eos_id=-1)   # warm-up
+        t1 = time.time()
+        O.decoder_generate(sdn, c, prompt, torch.ones(1, 64), max_len=1, pos_type="rope", attn_type=None,
+                           use_cache=True, use_static_cache=True, eos_id=-1)
+        t_pre = time.time() - t1
+        t1 = time.time()
+        O.decoder_generate(sdn, c, prompt, torch.ones(1, 64), max_len=new, pos_type="rope", attn_type=None,
+                           use_cache=True, use_static_cache=True, eos_id=-1)
+        t_all = time.time() - t1
+    dec = (new - 1) / max(t_all - t_pre, 1e-9)
     return {"value": round(n * B * seq / dt, 1), "unit": "tokens/s", "cores": nthreads, "kind": "port",
-            "sample": f"{n} fwd+bwd passes of the 12L decoder oracle at B={B} x seq={seq}, fp32, no optimizer step"}
+            "sample": f"{n} fwd+bwd passes of the 12L decoder oracle at B={B} x seq={seq}, fp32, no optimizer step",
+            "decode": {"value": round(dec, 1), "unit": "tokens/s",
+                       "sample": f"B=1 greedy decode, static cache, {new} tokens behind a 64-token prompt (token loop only)"}}
 
 
 def main():
@@ -272,9 +326,24 @@ def main():
             if world > 1:
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             per_tok = float(tm.item())
+            # decode roofline (HBM): per token step every layer / head weight once (the embedding table only B
+            # rows) + the K/V cache of the average context of the timed steps, over the measured step time
+            d_, nl = cfg.hidden_size, cfg.num_hidden_layers
+            hk = getattr(cfg, "num_key_value_heads", cfg.num_attention_heads) if a.attn == "gqa" else cfg.num_attention_heads
+            wbytes = (nl * 12 * d_ * d_ + d_ * d_ + cfg.vocab_size * d_) * 2
+            if a.attn == "gqa":
+                wbytes -= nl * 2 * d_ * (d_ - hk * (d_ // cfg.num_attention_heads)) * 2
+            ctx = L + (a.decode_tokens + 1) / 2.0
+            kvbytes = 2 * nl * B * ctx * hk * (d_ // cfg.num_attention_heads) * 2
             dec = {"tokens_per_sec": round(world * B / per_tok, 1), "ms_per_token_step": round(per_tok * 1e3, 3),
                    "prefill_plus_first_token_ms": round(t1 * 1e3, 2), "batch": B, "prompt": L,
-                   "new_tokens": a.decode_tokens, "cache": "StaticCacheOne", "scaling": "replicas only"}
+                   "new_tokens": a.decode_tokens, "cache": "StaticCacheOne", "scaling": "replicas only",
+                   "roofline": {"bound": "hbm", "achieved": round((wbytes + kvbytes) / per_tok * 1e-9, 1),
+                                "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round((wbytes + kvbytes) / per_tok * 1e-9 / PEAK_HBM_GBS, 4),
+                                "bytes_per_step": int(wbytes + kvbytes),
+                                "note": "algorithmic bytes: weights once (249 MB) + K/V of the mean context; ~88 dependent "
+                                        "launches per step, each bound by its own latency, not by bandwidth (DESIGN section 3)"}}
         model.train()
 
     roof = cpu = None
@@ -283,20 +352,27 @@ def main():
         roof = roofline_probe(cfg, B, L, dev)
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(cfg, L)
-        if world == 1 and not a.no_other_configs:
-            # the other BASELINE.json configurations, measured beside the headline (never part of `value`):
-            # the training model is released first; a failure here leaves a note, not a broken bench line
-            del trainer, model
+    if not a.no_other_configs:
+        # the other BASELINE.json configurations, measured beside the headline (never part of `value`):
+        # the training model is released first; a failure here leaves a note, not a broken bench line.
+        # configs[3] (caption training, "B=64 on 1->8 GPUs") runs on every rank under the same process group;
+        # configs[4] (single-sequence decode) on one GPU only.
+        del trainer, model
+        torch.cuda.empty_cache()
+        others = {}
+        todo = [("configs[3]", "tools.bench_vlm_training")]
+        if world == 1:
+            todo.append(("configs[4]", "tools.bench_paligemma"))
+        for key, mod in todo:
+            try:
+                import importlib
+                with contextlib.redirect_stdout(sys.stderr):
+                    others[key] = importlib.import_module(mod).run()
+            except Exception as ex:   # noqa: BLE001
+                others[key] = {"error": f"{type(ex).__name__}: {ex}"}
+                if world > 1:
+                    raise   # the ranks must not diverge inside a collective
             torch.cuda.empty_cache()
-            others = {}
-            for key, mod in (("configs[3]", "tools.bench_vlm_training"), ("configs[4]", "tools.bench_paligemma")):
-                try:
-                    import importlib
-                    with contextlib.redirect_stdout(sys.stderr):
-                        others[key] = importlib.import_module(mod).run()
-                except Exception as ex:   # noqa: BLE001
-                    others[key] = {"error": f"{type(ex).__name__}: {ex}"}
-                torch.cuda.empty_cache()
     if rank == 0:
         d = cfg.hidden_size
         fl_step = 3.0 * (block_flops_per_token(d, L) * cfg.num_hidden_layers + 2 * d * d + 2 * d * cfg.vocab_size) * B * L

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(new_tokens: int = 64, dev=None):
-    from tests.golden import cases
+    from vyomai_amd import shapes as cases
     from vyomai_amd.models import paligemma as P
     dev = dev or torch.device("cuda", 0)
     torch.manual_seed(0)

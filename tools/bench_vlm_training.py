@@ -5,21 +5,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run(B: int = 64, steps: int = 4, dev: str = "cuda"):
+    """One process per GPU: under torch.distributed every rank runs B images per step (weak scaling), gradients go
+    through the trainer's bucketed all-reduce; the time is the maximum over the ranks, the rates are whole-job."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
     import vyomai_amd as V
     from vyomai_amd import recipe
     from vyomai_amd.training import FlatTrainer
-    from tests.golden import cases
-    vcfg = cases.vit_cfg()
-    vcfg.num_hidden_layers = 12          # ViT-B/16: 12 layers, d = 768, 12 heads, MLP 3072, 197 tokens
-    cfg = cases.test_cfg()
-    cfg.num_hidden_layers, cfg.hidden_dropout_prob = 12, 0.0
-    if hasattr(vcfg, "hidden_dropout_prob"):
-        vcfg.hidden_dropout_prob = 0.0
+    from vyomai_amd.shapes import vit_b16_config
+    vcfg = vit_b16_config(12, 0.0)       # ViT-B/16: 12 layers, d = 768, 12 heads, MLP 3072, 197 tokens
+    cfg = V.EncoderConfig(num_hidden_layers=12, hidden_dropout_prob=0.0)
     vlm = V.VisionLanguageModel(cfg, V.Vit(vcfg), "rope", None)
     recipe.load_recipe_(vlm)
     vlm = vlm.to(dev).train()
-    img = torch.from_numpy(recipe.uniform("vit.img", (B, 3, 224, 224), 0.5, 0.5)).to(dev).to(torch.bfloat16)
-    ids = torch.from_numpy(recipe.token_ids("cap.ids", (B, 32), 3, cfg.vocab_size)).to(dev)
+    img = torch.from_numpy(recipe.uniform(f"vit.img.{rank}", (B, 3, 224, 224), 0.5, 0.5)).to(dev).to(torch.bfloat16)
+    ids = torch.from_numpy(recipe.token_ids(f"cap.ids.{rank}", (B, 32), 3, cfg.vocab_size)).to(dev)
     tr = FlatTrainer(vlm, lr=1e-4)
 
     def loss_fn():
@@ -29,20 +30,30 @@ def run(B: int = 64, steps: int = 4, dev: str = "cuda"):
             return torch.nn.functional.cross_entropy(lg, ids[:, 1:].reshape(-1))
         return vlm.caption_loss(img, ids)     # the same loss with the head and the cross-entropy fused
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     losses = []
     for s in range(2 + steps):
         if s == 2:
-            torch.cuda.synchronize(); t0 = time.time()
+            barrier(); t0 = time.time()
         losses.append(tr.train_step(loss_fn).item())
-    torch.cuda.synchronize()
+    barrier()
     dt = (time.time() - t0) / steps
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
     return {"workload": "configs[3]: ViT-B/16 (12L, 224x224/16, 197 tokens) + 12L d=768 vision-language decoder (33 tokens), caption training, AdamW, bf16 kernels + fp32 masters",
-            "batch": B, "ms_per_step": round(dt * 1e3, 2), "images_per_sec": round(B / dt, 1),
-            "decoder_tokens_per_sec": round(B * 33 / dt, 1), "losses": [round(x, 4) for x in losses]}
+            "batch_per_gpu": B, "n_gpus": world, "ms_per_step": round(dt * 1e3, 2), "images_per_sec": round(world * B / dt, 1),
+            "decoder_tokens_per_sec": round(world * B * 33 / dt, 1), "scaling": "weak",
+            "losses": [round(x, 4) for x in losses]}
 
 
 if __name__ == "__main__":
     r = run(int(os.environ.get("B", "64")))
     print("losses", r["losses"])
-    print(f"caption training B={r['batch']}: {r['ms_per_step']:.1f} ms/step, {r['images_per_sec']:.0f} images/s, "
+    print(f"caption training B={r['batch_per_gpu']}: {r['ms_per_step']:.1f} ms/step, {r['images_per_sec']:.0f} images/s, "
           f"{r['decoder_tokens_per_sec']:.0f} decoder tokens/s")

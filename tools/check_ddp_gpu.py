@@ -8,15 +8,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vyomai_amd as V
 from vyomai_amd import recipe
 from vyomai_amd.training import FlatTrainer
-from tests.golden import cases
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
-cfg = cases.with_kv(cases.test_cfg(), None)
-cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size = 3, 512, 8, 2048
-cfg.hidden_dropout_prob, cfg.vocab_size = 0.0, 1000
+cfg = V.EncoderConfig(num_hidden_layers=3, hidden_size=512, num_attention_heads=8, intermediate_size=2048,
+                      hidden_dropout_prob=0.0, vocab_size=1000, max_position_embeddings=1024)
 B, L, STEPS = 8, 512, 3
 all_ids = torch.from_numpy(recipe.token_ids("ddp.ids", (world * B, L), 3, cfg.vocab_size)).to(dev)
 
@@ -45,14 +43,13 @@ if rank == 0:
     assert all(torch.equal(gathered[0], g) for g in gathered[1:]), "ranks diverged"
     dist.destroy_process_group()
     ref = make()
-    # one process, both ranks' batches: gradient accumulation over two micro-batches = the average DDP takes
-    tr2 = FlatTrainer(ref, lr=1e-3, bucket_bytes=4 << 20, overlap_optimizer=False)   # (it accumulates two backward passes)
+    # one process, both ranks' batches: gradient accumulation over `world` micro-batches = the average DDP takes
+    tr2 = FlatTrainer(ref, lr=1e-3, bucket_bytes=4 << 20, accumulate_steps=world)
     for _ in range(STEPS):
-        tr2.zero_grad()
         for r in range(world):
             ids = all_ids[r * B:(r + 1) * B]
-            tr2.backward(ref.clm_loss(ids, ids) / world)
-        tr2.optimizer_step()
+            tr2.train_step(lambda: ref.clm_loss(ids, ids))
+    assert tr2.step_count == STEPS
     torch.cuda.synchronize()
     want = tr2.arena.master.detach().cpu()
     err = (flat - want).abs().max().item()
@@ -62,11 +59,11 @@ if rank == 0:
     print("mean |dp - ref| =", (flat - want).abs().mean().item())
     assert (flat - want).abs().mean().item() < 1e-5
     ref0 = make()
-    tr3 = FlatTrainer(ref0, lr=1e-3, bucket_bytes=4 << 20, overlap_optimizer=False)
+    tr3 = FlatTrainer(ref0, lr=1e-3, bucket_bytes=4 << 20, overlap_optimizer=False, accumulate_steps=world)
     tr3.zero_grad()
     for r in range(world):
         ids = all_ids[r * B:(r + 1) * B]
-        tr3.backward(ref0.clm_loss(ids, ids) / world)
+        tr3.backward(ref0.clm_loss(ids, ids))
     torch.cuda.synchronize()
     g_ref = tr3.arena.grad.detach().cpu()
     gerr = (g_dp - g_ref).abs().max().item() / g_ref.abs().max().item()

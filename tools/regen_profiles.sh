@@ -1,0 +1,22 @@
+#!/bin/bash
+# Regenerate the rocprofv3 evidence under profiles/ for round $1 (e.g. r02).  Run on the GPU box:
+#   gpurun -- 'bash tools/regen_profiles.sh r02'
+# then, back in the build container:  python tools/collect_profiles.py r02
+# Counters are collected in their own passes (kernel-trace / stats and --pmc are never combined; FETCH_SIZE and
+# WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots).
+set -e
+R=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/roofline -o rp -- python3 $ROOT/tools/roofline_probe.py > $OUT/roofline.log 2>&1
+echo "roofline probe traced"
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python3 $ROOT/tools/roofline_probe.py > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 $ROOT/tools/roofline_probe.py > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_hit -o p -- python3 $ROOT/tools/roofline_probe.py > /dev/null 2>&1
+echo "pmc passes done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/decode -o dec -- python3 $ROOT/tools/bench_decode_step.py --iters 20 > $OUT/decode.log 2>&1
+echo "decode step traced"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o b -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench.log 2>&1
+echo "bench traced"

@@ -1079,6 +1079,49 @@ extern "C" int vy_sumsq(const float* x, int64_t n, float* out, float* ws, void* 
   return VY_OK;
 }
 
+// ---- measured ceilings for the roofline report (not part of include/vyom_hip.h) ----------------------------
+// The matrix pipe alone: 8 waves per CU, six independent mfma_f32_32x32x16_bf16 chains per wave on lane-dependent
+// (non-trivial) operands, no memory traffic.  FLOPs = workgroups * 8 * iters * 6 * 2 * 32 * 32 * 16.
+__global__ __launch_bounds__(512) void mfma_peak_kernel(int iters, float* __restrict__ sink) {
+  bf16x8 a, b;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    a[e] = (bf16)(0.001f * (float)(((lane * 7 + e * 13 + blockIdx.x) % 97) - 48));
+    b[e] = (bf16)(0.002f * (float)(((lane * 11 + e * 5 + threadIdx.x) % 89) - 44));
+  }
+  f32x16 acc[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[c], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) s += acc[c][0] + acc[c][7];
+  if (s == 12345.678f) sink[0] = s;
+}
+extern "C" int vy_debug_mfma_peak(int workgroups, int iters, float* sink, void* stream) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, iters, sink);
+  VY_CHECK_LAUNCH("vy_debug_mfma_peak");
+  return VY_OK;
+}
+// A plain 16-byte-per-lane copy (read n bytes + write n bytes).
+__global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n16) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+extern "C" int vy_debug_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+  if (!src || !dst || bytes % 16) VY_FAIL(VY_ERR_ARG, "vy_debug_copy: bad arguments");
+  hipLaunchKernelGGL(copy16_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
+  VY_CHECK_LAUNCH("vy_debug_copy");
+  return VY_OK;
+}
+
 // ---- dropout as its own pass: y = x * keep(seed, offset, row, column) / (1 - p) ------------------
 // The forward applies the mask inside the GEMM epilogue (vy_linear_dropout_fwd); backward applies the SAME
 // mask to the incoming gradient here before the dgrad / wgrad GEMMs (their operands go to LDS by DMA and
