@@ -303,3 +303,30 @@ def test_gemm_two_workgroups_per_cu_variants(variant):
             assert torch.allclose(y1.double(), want, atol=3e-2, rtol=1e-2)
     finally:
         lib.vy_debug_set_gemm_variant(-1)
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_pipelined_epilogue_kernel(act):
+    """The persistent kernel that works the previous tile's epilogue off inside the next tile's k-loop (default for
+    whole-tile launches with >= 2 tiles per CU and a plain epilogue) against the one-shot kernels, bit for bit
+    (variant 31 = the default selection without it), and against fp64."""
+    import ctypes as C
+    from vyomai_amd import ops, _lib
+    lib = _lib.load()
+    lib.vy_debug_set_gemm_variant.argtypes = [C.c_int]
+    try:
+        for M, N, K in ((8192, 3072, 768), (16384, 2304, 832), (5120, 4992, 1024)):
+            x = rnd(M, K, seed=1).to(BF).to(DEV)
+            w = rnd(N, K, seed=2, scale=1 / math.sqrt(K)).to(BF).to(DEV)
+            b = rnd(N, seed=3, scale=0.1).to(BF).to(DEV)
+            lib.vy_debug_set_gemm_variant(31)
+            y0 = ops.linear(x, w, b, act=act)
+            lib.vy_debug_set_gemm_variant(-1)
+            y1 = ops.linear(x, w, b, act=act)
+            assert torch.equal(y0, y1), (M, N, K)
+            rows = slice(0, M, 37)
+            pre = x[rows].double() @ w.double().t() + b.double()
+            want = O.gelu_erf(pre) if act else pre
+            assert torch.allclose(y1[rows].double(), want, atol=3e-2, rtol=1e-2)
+    finally:
+        lib.vy_debug_set_gemm_variant(-1)

@@ -52,25 +52,29 @@ def main():
     def mk():
         q = torch.empty(B, h, L, dh, dtype=bf, device=dev)
         return dict(q=q, k=torch.empty_like(q), v=torch.empty_like(q), s1=torch.empty(M, d, dtype=bf, device=dev),
-                    hm=torch.empty(M, 4 * d, dtype=bf, device=dev), s2=torch.empty(M, d, dtype=bf, device=dev))
+                    hm=torch.empty(M, 4 * d, dtype=bf, device=dev), s2=torch.empty(M, d, dtype=bf, device=dev),
+                    hm2=torch.empty(M, 4 * d, dtype=bf, device=dev), pre=torch.empty(M, 4 * d, dtype=bf, device=dev),
+                    qkvp=torch.empty(M, 3 * d, dtype=bf, device=dev))
 
     launches = {
         "qkv+rope": lambda o: ops.qkv_rope(x3, wqkv, bqkv, h, h, dh, cos, sin, 0, o["q"], o["k"], o["v"]),
         "out+res": lambda o: ops.linear(x, wo, bo, residual=x, out=o["s1"]),
         "ffn1+gelu": lambda o: ops.linear(x, w1, b1, act=1, out=o["hm"]),
+        "ffn1+gelu+pre": lambda o: ops.linear(x, w1, b1, act=1, out=o["hm2"], pre_out=o["pre"]),
+        "qkv plain": lambda o: ops.linear(x, wqkv, bqkv, out=o["qkvp"]),
         "ffn2+res": lambda o: ops.linear(hm_in, w2, b2, residual=x, out=o["s2"]),
     }
     flops = {"qkv+rope": 2.0 * M * 3 * d * d, "out+res": 2.0 * M * d * d, "ffn1+gelu": 2.0 * M * 4 * d * d,
-             "ffn2+res": 2.0 * M * 4 * d * d}
+             "ffn2+res": 2.0 * M * 4 * d * d, "ffn1+gelu+pre": 2.0 * M * 4 * d * d, "qkv plain": 2.0 * M * 3 * d * d}
     # correctness: every variant against the default selection, bit for bit (same arithmetic order per
     # output element: one accumulation chain over k in slices, fp32)
-    setvar(-1)
+    setvar(31 if 31 in variants else -1)
     ref = mk()
     for f in launches.values():
         f(ref)
     torch.cuda.synchronize()
     for v in variants:
-        if v == -1:
+        if v == (31 if 31 in variants else -1):
             continue
         setvar(v)
         o = mk()

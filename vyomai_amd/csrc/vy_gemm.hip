@@ -766,6 +766,250 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// PERSISTENT 256 x 192 kernel with the epilogue of tile t software-pipelined into the k-loop of tile t+1.
+//
+// Measured on the forward launches of a layer (tools/gemm_diag2.py, workgroup 0, K = 768): the k-loop is 34 k
+// cycles, the epilogue 12 k (plain), 21 k (+GELU or +residual), 24 k (+RoPE): a third of every launch is spent
+// with the matrix pipe idle while ALL 256 workgroups convert, stage and store at once.  Here a workgroup keeps
+// its CU for several tiles; when a tile's last k-slice is done its accumulators (+ bias) are packed to bf16 in
+// REGISTERS (96 fp32 -> 48 packed registers, still two waves per SIMD) and the workgroup goes straight on to
+// the next tile; during that tile's first 12 k-stages every wave works off one parked pair of quads per stage:
+// activation, v_permlane32_swap so that a lane holds 8 consecutive columns, one 16-byte store.
+//   * the two waves of a SIMD run the same program in lockstep (one barrier per stage): waves 0-3 drain
+//     behind k-step 0, waves 4-7 behind k-step 2 (MI355X_MICROARCH.md, two waves per SIMD, item 9);
+//   * the parked value is made opaque (empty asm) at the drain point, or the compiler applies the activation
+//     when it parks -- the serial epilogue again;
+//   * (a variant that transposed the parked tile through a per-wave LDS scratch to store whole 128-byte lines
+//     measured slower than no pipelining at all: 2-stage ring + scratch traffic.)
+// The parked tile's global stores are issued AFTER the stage's LDS-DMA (younger in the wave's memory queue)
+// and counted in the stage's vmcnt, so the wait for the next slice never waits for a store.  Only the LAST
+// tile of a workgroup runs the staged LDS epilogue.  A launch with one tile per CU gains nothing (the launcher
+// keeps the one-shot kernel for those).  Arithmetic is that of gemm_epilogue (bias -> bf16 -> activation on
+// the bf16 value -> bf16): bit-identical.
+// ------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pipe_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, int tiles_total, EpiPlain<bf16> ep, int knob) {
+  constexpr int BM = 256, BN = 192, WGM = 4, WGN = 2, NW = 8;
+  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);   // 2, 3
+  constexpr int PX = BM / 8, PW = BN / 8;
+  constexpr int GX = PX / NW, GW = PW / NW;                  // 4, 3
+  constexpr int XT = BM * ROWB, WT = BN * ROWB;
+  constexpr int WOFF = 3 * XT;
+  constexpr int EROW = BN * 2 + 16;
+  constexpr int LDS_BYTES = 3 * XT + 2 * WT > BM * EROW ? 3 * XT + 2 * WT : BM * EROW;
+  constexpr int NP = TN * TM * 2;            // 12 pairs of quads (8 columns) per lane and tile
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
+  const int lrow = lane >> 3, slot = lane & 7;
+  const int KT = K / BK;   // the launcher guarantees K % 64 == 0, KT >= 12, whole tiles
+
+  unsigned xa[4], wa[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
+    xa[ks] = vy_lds_addr(smem) + (wm * 32 * TM + fr) * ROWB + coff;
+    wa[ks] = vy_lds_addr(smem) + WOFF + (wn * 32 * TN + fr) * ROWB + coff;
+  }
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; w_[i] = vy_lds_read128_off<i * 32 * ROWB>(wbase); });
+    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; x_[j] = vy_lds_read128_off<j * 32 * ROWB>(xbase); });
+  };
+  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) vy_tie(w_[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) vy_tie(x_[j]);
+  };
+
+  f32x16 acc[TN][TM];
+  // the previous tile, bf16(acc + bias): pair p = (i * TM + j) * 2 + h holds the quads rg = 2h and 2h + 1
+  u32x2 parked[NP][2];
+  bool have_parked = false;   // workgroup-uniform
+  int pm0 = 0, pn0 = 0;
+
+  // one parked pair (two quads, 8 output columns), worked off over the four k-steps of one stage: k-step s
+  // applies the activation to element s of both quads -- a few VALU instructions that the scheduler is told
+  // to interleave with that k-step's six MFMAs (sched_group_barrier), because a wave issues in order: a
+  // VALU block between two MFMA clusters delays the second cluster by its whole length -- and k-step 3 ends
+  // with the lane-half swap (T21: v_permlane32_swap, a lane then holds 8 consecutive columns) and one
+  // 16-byte store.
+  bf16x4 da, db;   // the pair in flight
+  auto drain_begin = [&](auto p_c) {
+    constexpr int P = decltype(p_c)::value;
+    u32x2 a = parked[P][0], b = parked[P][1];
+    // the compiler must not do this work at park time (it would be the old serial epilogue again)
+    asm volatile("" : "+v"(a), "+v"(b));
+    da = __builtin_bit_cast(bf16x4, a);
+    db = __builtin_bit_cast(bf16x4, b);
+  };
+  auto drain_step = [&](int e) {
+    if constexpr (ACT != VY_ACT_NONE) {
+      da[e] = (bf16)vy_act_fwd_fast<ACT>((float)da[e]);
+      db[e] = (bf16)vy_act_fwd_fast<ACT>((float)db[e]);
+    }
+  };
+  auto drain_end = [&](auto p_c) {
+    constexpr int P = decltype(p_c)::value;
+    constexpr int i = P / (TM * 2), j = (P / 2) % TM, hq = P % 2;
+    const u32x2 a = __builtin_bit_cast(u32x2, da), b = __builtin_bit_cast(u32x2, db);
+    // vdst = quad rg (a), src = quad rg + 1 (b): lanes 32-63 of a swap with lanes 0-31 of b
+    auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+    const int64_t m = pm0 + wm * 32 * TM + j * 32 + fr;
+    const int n = pn0 + wn * 32 * TN + i * 32 + 16 * hq + 8 * fh;
+    *reinterpret_cast<u32x4*>(ep.y + m * ep.ldy + n) = o;
+  };
+
+  for (int b = blockIdx.x; b < tiles_total; b += gridDim.x) {
+    const int wg = xcd_remap(b, tiles_total);
+    const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16* xsrc[GX];
+    const bf16* wsrc[GW];
+#pragma unroll
+    for (int t = 0; t < GX; ++t) {
+      const int R = (wave + NW * t) * 8 + lrow;
+      xsrc[t] = X + (int64_t)(m0 + R) * ldx + (slot ^ ((R >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < GW; ++t) {
+      const int R = (wave + NW * t) * 8 + lrow;
+      wsrc[t] = W + (int64_t)(n0 + R) * ldw + (slot ^ ((R >> 1) & 7)) * 8;
+    }
+    auto stage_x = [&](int kt) {
+      char* xb = smem + (kt % 3) * XT;
+#pragma unroll
+      for (int t = 0; t < GX; ++t)
+        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(xsrc[t] + kt * BK), (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, 0, 0);
+    };
+    auto stage_w = [&](int kt) {
+      char* wb = smem + WOFF + (kt & 1) * WT;
+#pragma unroll
+      for (int t = 0; t < GW; ++t)
+        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(wsrc[t] + kt * BK), (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // (every wave passed the barrier that ended the previous tile's last stage: its LDS reads are retired)
+    stage_x(0);
+    stage_w(0);
+    stage_x(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(wa[0], xa[0], wf[0], xf[0]);
+    int xbuf = 0;   // kt % 3
+    int kt = 0;
+    // one k-stage; DR: one parked pair (16 output bytes per lane) rides between its k-steps
+    auto stage_body = [&](auto dr_c, auto p_c) {
+      constexpr bool DR = decltype(dr_c)::value;
+      if (kt + 1 < KT) stage_w(kt + 1);
+      if (kt + 2 < KT) stage_x(kt + 2);
+      const unsigned xo = xbuf * XT, wo = (kt & 1) * WT;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+          read_frags(wa[ks + 1] + wo, xa[ks + 1] + xo, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        tie_frags(wf[ks & 1], xf[ks & 1]);
+        if constexpr (DR && ACT != VY_ACT_NONE) {
+          // activation of element ks of the pair in flight, interleaved with this k-step's MFMAs
+          if (ks == 0) drain_begin(p_c);
+          drain_step(ks);
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < TN * TM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // then up to 7 VALU
+            __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);   // and a transcendental
+          }
+          if (ks == 3) drain_end(p_c);
+        } else {
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          if constexpr (DR) {
+            if (ks == 0) { drain_begin(p_c); drain_end(p_c); }
+          }
+        }
+      }
+      // oldest first: X(kt+1), W(kt+1), X(kt+2), this stage's parked store
+      if constexpr (DR) {
+        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      xbuf = xbuf == 2 ? 0 : xbuf + 1;
+      if (kt + 1 < KT) read_frags(wa[0] + (WT - wo), xa[0] + xbuf * XT, wf[0], xf[0]);
+      ++kt;
+    };
+    if (have_parked) {
+      vy_static_for<NP>([&](auto p_c) { stage_body(std::true_type{}, p_c); });
+      have_parked = false;
+    }
+    while (kt < KT) stage_body(std::false_type{}, std::integral_constant<int, 0>{});
+
+    if (b + (int)gridDim.x < tiles_total) {
+      // more tiles for this workgroup: park bf16(acc + bias) in registers and go on
+      const bf16* biasp = ep.bias;
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          float bq[4] = {0.f, 0.f, 0.f, 0.f};
+          if (biasp) {
+            const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(biasp + n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bq[e] = (float)b4[e];
+          }
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            bf16x4 w4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w4[e] = (bf16)(acc[i][j][4 * rg + e] + bq[e]);
+            parked[(i * TM + j) * 2 + (rg >> 1)][rg & 1] = __builtin_bit_cast(u32x2, w4);
+          }
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the bias loads; the last parked store)
+      have_parked = true;
+      pm0 = m0; pn0 = n0;
+    } else {
+      // last tile of this workgroup: the staged epilogue (the ring is free: every wave is past the last barrier)
+      EpiQkv<bf16> eq{};
+      gemm_epilogue<BM, BN, WGM, WGN, 0, ACT, false>(acc, smem, m0, n0, M, N, ep, eq);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // 256 x 192 tile on FOUR waves (2 x 2, 128 x 96 per wave, 192 accumulator registers), k-slices of 32
 // with X in a three-deep and W in a two-deep LDS ring: 72 KiB, so TWO workgroups are resident per CU.
 // Why: with one 8-wave workgroup per CU every wave of the CU is in the same phase -- all issue their
@@ -1771,6 +2015,22 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
                        N * ldw * 2 < (int64_t)0xffffffffll;
     static const int pp_min_n = [] { const char* e = getenv("VY_GEMM_PP_MIN_N"); return e ? atoi(e) : 0; }();
     if ((var == 20 || var == 21) && !(pp_ok && N >= pp_min_n)) var = 14;
+    // persistent kernel with the epilogue pipelined into the next tile's k-loop: whole tiles, K a multiple of 64
+    // and >= 12 stages, plain epilogue without residual / dropout, and at least two tiles per CU
+    static const int pipe_env = [] { const char* e = getenv("VY_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    int pipe_on = pipe_env;
+    if (var == 31) { var = 14; pipe_on = 0; }   // the default selection without the pipelined kernel (A/B runs, tests)
+    if constexpr (EPI == 0 && !GRAD) {
+      const int64_t tiles = (M / 256) * (N / 192);
+      if ((var == 14 || var == 30) && pipe_on && M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && K >= 768 &&
+          tiles >= 2 * 256 && !ep.residual && !ep.residual2 && !ep.drop.thr && ep.vec_ok && !ep.pre) {
+        static const int pipe_knob = [] { const char* e = getenv("VY_GEMM_PIPE_KNOB"); return e ? atoi(e) : 0; }();
+        const int g = (int)(tiles < 256 ? tiles : 256);
+        hipLaunchKernelGGL((gemm_nt_bf16_pipe_kernel<ACT>), dim3(g), dim3(512), 0, st, X, ldx, W, ldw, (int)M, (int)N,
+                           (int)K, (int)(N / 192), (int)tiles, ep, pipe_knob);
+        return 0;
+      }
+    }
     if (var == 20 || var == 21) {   // 4-wave 256 x 192 tiles, two workgroups per CU
       if (var == 20)
         hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI, ACT, GRAD, 0>), dim3(tm * tn), dim3(256), 0,
