@@ -123,6 +123,10 @@ from vyomai_amd.shapes import (attn_shapes, aso_shapes, ffn_shapes, layer_shapes
                                siglip_layer_shapes, gemma_layer_shapes)
 
 
+# reduced vocabulary of the PaliGemma model golden (true widths, 2 + 2 layers); the image placeholder id
+PG_SMALL_VOCAB, PG_IMAGE_TOKEN = 4099, 4000
+
+
 # ---- sampling processors / speculative decoding ----------------------------------
 
 def sampling_logits() -> np.ndarray:

@@ -386,6 +386,71 @@ def paligemma_blocks():
 
 
 # ---------------------------------------------------------------------------
+# E2. the PaliGemma MODEL and its cached greedy loop: notebook cells 9, 11-13, 15-17 (classes) and 28 (the
+#     notebook's StaticCache on transformers.cache_utils.Cache) exec'd at the true widths with reduced depth
+#     (2 SigLIP + 2 Gemma layers) and a small vocabulary; test_inference (cell 30) restated line by line around
+#     them (it needs the remote processor only to build the inputs, which are synthetic here).
+# ---------------------------------------------------------------------------
+
+
+def paligemma_model():
+    import json
+    import logging
+    import math
+    import typing
+    from einops import rearrange
+    nb = json.load(open("/root/reference/Examples/paligemma.ipynb"))
+    ns = {"rearrange": rearrange, "math": math, "logger": logging.getLogger("pg"), "Optional": Optional,
+          "Tuple": Tuple, "dataclass": dataclass, "torch": torch, "nn": torch.nn}
+    ns.update({k: getattr(typing, k) for k in ("List", "Union", "Dict", "Any")})
+    # The notebook's StaticCache (cell 28) derives from transformers.cache_utils.Cache only to call a
+    # no-argument super().__init__(); the transformers installed here (5.x) made that constructor take the
+    # layer list, so the base is an empty class here and the cell's own import line is dropped.  Everything the
+    # loop uses -- update() with cache_position, get_seq_length(), get_max_length() -- is the cell's own code.
+    class Cache:   # noqa: D401
+        def __init__(self):
+            pass
+    ns["Cache"] = Cache
+    for i in (9, 11, 12, 13, 15, 16, 17, 28):
+        src = "".join(nb["cells"][i]["source"]).replace("from transformers.cache_utils import Cache\n", "")
+        exec(src, ns)
+    vis = dict(cases.SIGLIP, num_hidden_layers=2)
+    txt = {k: v for k, v in cases.GEMMA.items() if k != "pad_token_id"}
+    txt.update(num_hidden_layers=2, vocab_size=cases.PG_SMALL_VOCAB)
+    cfg = ns["PaliGemmaConfig"](vision_config=vis, text_config=txt, image_token_index=cases.PG_IMAGE_TOKEN,
+                                vocab_size=cases.PG_SMALL_VOCAB, projection_dim=2048, hidden_size=2048, pad_token_id=0)
+    model = ns["PaliGemmaForConditionalGeneration"](cfg)
+    model.tie_weights()
+    filled(model, "pgm.")
+    n_img = (vis["image_size"] // vis["patch_size"]) ** 2
+    img = T(recipe.uniform("pgm.img", (1, 3, 224, 224), 0.5, 0.5))
+    text = T(recipe.token_ids("pgm.ids", (1, 8), 3, cases.PG_IMAGE_TOKEN))
+    input_ids = torch.cat([torch.full((1, n_img), cases.PG_IMAGE_TOKEN, dtype=torch.long), text], dim=1)
+    attention_mask = torch.ones_like(input_ids)
+    out = {}
+    # cell 30, test_inference, greedy branch
+    cache = ns["StaticCache"](cfg.text_config, batch_size=1, device="cpu", dtype=torch.float32, max_cache_len=288)
+    generated = []
+    ids, am, pv = input_ids, attention_mask, img
+    for step in range(8):
+        o = model(input_ids=ids, pixel_values=pv, attention_mask=am, past_key_values=cache, use_cache=True)
+        cache = o.past_key_values
+        logits = o.logits[:, -1, :]
+        if step < 3:
+            out[f"logits.step{step}"] = logits
+        if step == 0:
+            out["prefill.logits.sub"] = o.logits[0, ::7, ::5]
+            out["image_features"] = cases.sub2(o.image_hidden_states[0])
+        nxt = torch.argmax(logits, dim=-1, keepdim=True)
+        generated.append(nxt.squeeze(0))
+        ids = nxt
+        am = torch.cat([am, torch.ones((1, 1))], dim=-1)
+        pv = None if False else pv   # the notebook passes pixel_values on every call (cell 30)
+    out["generated"] = torch.cat(generated, dim=-1)
+    save("paligemma_model", **out)
+
+
+# ---------------------------------------------------------------------------
 # G. sampling processors and speculative decoding
 # ---------------------------------------------------------------------------
 
@@ -449,7 +514,7 @@ def sampling():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["modules", "models", "grads", "vgrads", "paligemma", "seq2seq", "sampling"]
+    which = sys.argv[1:] or ["modules", "models", "grads", "vgrads", "paligemma", "pgmodel", "seq2seq", "sampling"]
     if "modules" in which:
         module_level()
     if "models" in which:
@@ -460,6 +525,8 @@ if __name__ == "__main__":
         vision_gradients()
     if "paligemma" in which:
         paligemma_blocks()
+    if "pgmodel" in which:
+        paligemma_model()
     if "seq2seq" in which:
         seq2seq()
     if "sampling" in which:

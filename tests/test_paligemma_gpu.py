@@ -164,3 +164,42 @@ def test_generate_refuses_to_overrun_the_cache():
     with pytest.raises(ValueError):
         m.generate(img, ids, max_new_tokens=50, max_cache_len=300)     # 260 prefix + 49 > 300
     assert m.generate(img, ids, max_new_tokens=3, max_cache_len=300).shape == (1, 3)
+
+
+def test_model_and_cached_greedy_loop_fp32_vs_notebook(golden):
+    """The whole PaliGemma-shaped model -- SigLIP tower, projector (/ sqrt d), Gemma stack with 1-indexed rotary
+    positions, tied head -- and the notebook's cached greedy loop (cell 30 around the notebook's own StaticCache,
+    cell 28), at the true widths with 2 + 2 layers: logits to 2e-5 of the reference's, token ids bit-exact
+    (tests/golden/paligemma_model.npz, made by exec'ing the notebook cells)."""
+    from vyomai_amd.models import paligemma as P
+    g = golden("paligemma_model")
+    vis = P.SiglipVisionConfig(**dict(cases.SIGLIP, num_hidden_layers=2))
+    txt = types.SimpleNamespace(**dict(cases.GEMMA, num_hidden_layers=2, vocab_size=cases.PG_SMALL_VOCAB))
+    m = P.PaliGemmaForConditionalGeneration(P.PaliGemmaShape(vis, txt, txt.hidden_size))
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            ref_name = m.reference_name(n)
+            if ref_name.endswith("embed_tokens.weight"):
+                # the notebook ties lm_head.weight to the embedding table: one tensor under two state_dict keys,
+                # and the generator's fill wrote the later key's values last
+                ref_name = "language_model.lm_head.weight"
+            p.copy_(T(recipe.param_value("pgm." + ref_name, tuple(p.shape))))
+    m = m.to(DEV).eval()
+    img = T(recipe.uniform("pgm.img", (1, 3, 224, 224), 0.5, 0.5)).to(DEV)
+    ids = T(recipe.token_ids("pgm.ids", (1, 8), 3, cases.PG_IMAGE_TOKEN)).to(DEV)
+    with torch.no_grad():
+        feats = m.image_features(img)
+        close(cases.sub2(feats[0]), g["image_features"], 2e-5 * max(1.0, float(np.abs(g["image_features"]).max())),
+              "projected image features")
+        hidden = m.prefill(img, ids)
+        logits = m.lm_head(hidden)
+    scale = max(1.0, float(np.abs(g["prefill.logits.sub"]).max()))
+    close(logits[0, ::7, ::5], g["prefill.logits.sub"], 3e-5 * scale, "prefill logits")
+    close(logits[:, -1], g["logits.step0"], 3e-5 * scale, "first-token logits")
+    toks = m.generate(img, ids, max_new_tokens=8, max_cache_len=288)
+    assert np.array_equal(toks.cpu().numpy().reshape(-1), g["generated"].reshape(-1)), (toks, g["generated"])
+    # and a state_dict keyed like the notebook's modules loads
+    ref_sd = {m.reference_name(n): t.detach().clone() + 1.0 for n, t in m.state_dict().items()}
+    before = m.norm.weight.detach().clone()
+    m.load_reference_state_dict(ref_sd)
+    assert torch.allclose(m.norm.weight, before + 1.0)

@@ -210,7 +210,11 @@ class GemmaDecodePlan:
         p.ffn, p.vocab, p.dtype, p.eps = t.intermediate_size, t.vocab_size, _lib.dtype_code(dt), t.rms_norm_eps
         cos, sin = model.rope.on(dev)
         self.keep += [cos, sin]
-        p.cos_tab, p.sin_tab = cos.data_ptr(), sin.data_ptr()
+        # rotary positions are cache slot + ROPE_OFFSET (PaliGemma counts from 1): the step indexes the tables
+        # by cache slot, so hand it the tables shifted by that many rows
+        off = int(getattr(model, "ROPE_OFFSET", 0)) * cos.shape[-1] * cos.element_size()
+        assert cos.is_contiguous() and sin.is_contiguous() and cos.dim() >= 2
+        p.cos_tab, p.sin_tab = cos.data_ptr() + off, sin.data_ptr() + off
         p.layers = C.cast(arr, C.POINTER(VyGemmaLayer))
         p.norm_w, p.head_w = ptr(model.norm.weight), ptr(model.embed_tokens.weight)
         lib.vy_gemma_ws_bytes.restype = C.c_int64

@@ -177,7 +177,10 @@ class GemmaDecoderLayer(nn.Module):
         self.post_attention_layernorm = GemmaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, hidden_states: torch.Tensor, rope: Optional[RopeTable], start_pos: int = 0,
-                causal: bool = False, cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+                causal: bool = False, cache: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                pos_offset: int = 0) -> torch.Tensor:
+        """start_pos: the cache slot of the first token; the rotary position of token t is
+        start_pos + t + pos_offset (PaliGemma counts positions from 1: notebook cell 17, position_ids)."""
         a = self.self_attn
         B, L, _ = hidden_states.shape
         h, hk, dh = a.num_heads, a.num_key_value_heads, a.head_dim
@@ -191,7 +194,7 @@ class GemmaDecoderLayer(nn.Module):
         else:
             kw = torch.empty((B, hk, L, dh), dtype=n.dtype, device=n.device)
             vw = torch.empty_like(kw)
-        ops.qkv_rope(n, w, b, h, hk, dh, cos, sin, start_pos, q, kw, vw)
+        ops.qkv_rope(n, w, b, h, hk, dh, cos, sin, start_pos + pos_offset, q, kw, vw)
         if cache is not None:
             k_all, v_all = kc[:B, :, : start_pos + L], vc[:B, :, : start_pos + L]
         else:
@@ -229,6 +232,38 @@ class PaliGemmaForConditionalGeneration(nn.Module):
         self.norm = GemmaRMSNorm(t.hidden_size, eps=t.rms_norm_eps)
         self.rope = RopeTable(_angles(t.head_dim, t.max_position_embeddings, t.rope_theta))
 
+    # PaliGemma's rotary positions are 1-indexed: position_ids = cache_position + 1 (notebook cell 17)
+    ROPE_OFFSET = 1
+
+    # our parameter names -> the notebook model's (cells 9, 15-17), for checkpoints laid out like its modules
+    _REFERENCE_NAMES = (("vision_tower.patch_embedding.", "vision_tower.vision_model.embeddings.patch_embedding."),
+                        ("vision_tower.position_embedding.", "vision_tower.vision_model.embeddings.position_embedding."),
+                        ("vision_tower.layers.", "vision_tower.vision_model.encoder.layers."),
+                        ("vision_tower.post_layernorm.", "vision_tower.vision_model.post_layernorm."),
+                        ("multi_modal_projector.", "multi_modal_projector.linear."),
+                        ("embed_tokens.", "language_model.model.embed_tokens."),
+                        ("layers.", "language_model.model.layers."),
+                        ("norm.", "language_model.model.norm."))
+
+    @classmethod
+    def reference_name(cls, name: str) -> str:
+        """The notebook model's state_dict key of one of this module's parameters."""
+        for ours, theirs in cls._REFERENCE_NAMES:
+            if name.startswith(ours):
+                return theirs + name[len(ours):]
+        return name
+
+    def load_reference_state_dict(self, state_dict) -> None:
+        """Load a state_dict keyed like the notebook's PaliGemmaForConditionalGeneration (the tied
+        language_model.lm_head.weight, if present, is the embedding table)."""
+        own = self.state_dict()
+        missing = [n for n in own if self.reference_name(n) not in state_dict]
+        if missing:
+            raise KeyError(f"reference state_dict lacks {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+        with torch.no_grad():
+            for n, t in own.items():
+                t.copy_(state_dict[self.reference_name(n)])
+
     def lm_head(self, hidden: torch.Tensor) -> torch.Tensor:
         return ops.linear(hidden, self.embed_tokens.weight)  # tied (GemmaForCausalLM.tie_weights)
 
@@ -236,8 +271,23 @@ class PaliGemmaForConditionalGeneration(nn.Module):
         t = self.shape.text
         hidden = hidden * torch.tensor(t.hidden_size ** 0.5, dtype=hidden.dtype, device=hidden.device)
         for i, layer in enumerate(self.layers):
-            hidden = layer(hidden, self.rope, start_pos, causal=False, cache=None if caches is None else caches[i])
+            hidden = layer(hidden, self.rope, start_pos, causal=False, cache=None if caches is None else caches[i],
+                           pos_offset=self.ROPE_OFFSET)
         return self.norm(hidden)
+
+    def image_features(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """projector(vision tower) / sqrt(d) (notebook cell 17, get_image_features: the decoder multiplies every
+        input embedding by sqrt(d), image rows included)."""
+        dt = self.embed_tokens.weight.dtype
+        img = ops.linear(self.vision_tower(pixel_values.to(dt)), self.multi_modal_projector.weight,
+                         self.multi_modal_projector.bias)
+        return img / (self.shape.text.hidden_size ** 0.5)
+
+    @torch.no_grad()
+    def prefill(self, pixel_values: torch.Tensor, input_ids: torch.Tensor, caches=None) -> torch.Tensor:
+        """Hidden states (after the final norm) of the prefix [image tokens | text tokens]; K/V go into `caches`."""
+        hidden = torch.cat([self.image_features(pixel_values), self.embed_tokens(input_ids)], dim=1)
+        return self._decoder(hidden, 0, caches)
 
     @torch.no_grad()
     def generate(self, pixel_values: torch.Tensor, input_ids: torch.Tensor, max_new_tokens: int = 64,
@@ -245,9 +295,7 @@ class PaliGemmaForConditionalGeneration(nn.Module):
         t = self.shape.text
         dev, dt = pixel_values.device, self.embed_tokens.weight.dtype
         B = input_ids.shape[0]
-        img = ops.linear(self.vision_tower(pixel_values.to(dt)), self.multi_modal_projector.weight,
-                         self.multi_modal_projector.bias)
-        hidden = torch.cat([img, self.embed_tokens(input_ids)], dim=1)
+        hidden = torch.cat([self.image_features(pixel_values), self.embed_tokens(input_ids)], dim=1)
         if hidden.shape[1] + max_new_tokens - 1 > max_cache_len:
             raise ValueError(f"{hidden.shape[1]} prefix tokens + {max_new_tokens} new tokens exceed max_cache_len={max_cache_len}")
         caches = [(torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev),
