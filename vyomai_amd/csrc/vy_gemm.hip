@@ -1900,51 +1900,95 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
 // epilogue.  N/4 workgroups whatever the shape: the 32-column MFMA kernel above has N/32, i.e. 64 for
 // a 16384 -> 2048 down-projection, a quarter of the chip.
 // ------------------------------------------------------------------------------------------
-template <int EPI, int ACT, int MR>
+// NORM: the input rows are RMS-normalised on the way in (x * rsqrt(mean x^2 + eps) * (1 + w), rounded to bf16:
+// GemmaRMSNorm, notebook cell 11) -- every wave redoes the row statistics from the chunks it reads anyway
+// (the same lane -> chunk map and the same arithmetic as rmsnorm_fwd_kernel: bit-identical), which removes one
+// launch per projection from a single-sequence decode step.  GATED: W is the packed [gate; up] matrix
+// ([2 I, K]); the wave of output column n reads rows n and I + n and stores act(bf16 gate) * bf16 up
+// (GemmaMLP, cell 11; the arithmetic of gated_act_kernel on the two rounded projections).
+template <int EPI, int ACT, int MR, bool NORM = false, bool GATED = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx,
                                                         const bf16* __restrict__ W, int64_t ldw, int M, int N, int K,
-                                                        EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+                                                        EpiPlain<bf16> ep, EpiQkv<bf16> eq,
+                                                        const bf16* __restrict__ norm_w, float norm_eps) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;   // wave-uniform
   const bf16* w = W + (int64_t)n * ldw;
-  float acc[MR];
+  const bf16* w2 = GATED ? W + (int64_t)(N + n) * ldw : nullptr;
+  float acc[MR], acc2[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  for (int m = 0; m < MR; ++m) { acc[m] = 0.f; acc2[m] = 0.f; }
+  float rstd[MR];
+  if constexpr (NORM) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      float q = 0.f;
+      if (m < M) {
+        for (int kk = lane * 8; kk < K; kk += 512) {
+          const bf16x8 xv = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * ldx + kk);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) q += (float)xv[e] * (float)xv[e];
+        }
+      }
+      const float ms = vy_wave_sum(q) / (float)K + norm_eps;
+      float r = rsqrtf(ms);
+      rstd[m] = r * (1.5f - 0.5f * ms * r * r);
+    }
+  }
   constexpr int U = 8;
   for (int k0 = lane * 8; k0 < K; k0 += U * 512) {
-    bf16x8 wv[U];
+    bf16x8 wv[U], wv2[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = k0 + u * 512;
       wv[u] = *reinterpret_cast<const bf16x8*>(w + (kk < K ? kk : 0));
+      if constexpr (GATED) wv2[u] = *reinterpret_cast<const bf16x8*>(w2 + (kk < K ? kk : 0));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = k0 + u * 512;
       if (kk < K) {
-        union { bf16x8 v; bf16x2_t h[4]; } a, b;
+        union { bf16x8 v; bf16x2_t h[4]; } a, a2, b;
         a.v = wv[u];
+        if constexpr (GATED) a2.v = wv2[u];
+        bf16x8 g8;
+        if constexpr (NORM) g8 = *reinterpret_cast<const bf16x8*>(norm_w + kk);
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
           if (m < M) {
             b.v = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * ldx + kk);
+            if constexpr (NORM) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[m] = __builtin_amdgcn_fdot2_f32_bf16(a.h[e], b.h[e], acc[m], false);
+              for (int e = 0; e < 8; ++e) b.v[e] = (bf16)((float)b.v[e] * rstd[m] * (1.0f + (float)g8[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              acc[m] = __builtin_amdgcn_fdot2_f32_bf16(a.h[e], b.h[e], acc[m], false);
+              if constexpr (GATED) acc2[m] = __builtin_amdgcn_fdot2_f32_bf16(a2.h[e], b.h[e], acc2[m], false);
+            }
           }
         }
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < MR; ++m) acc[m] = vy_wave_sum(acc[m]);
+  for (int m = 0; m < MR; ++m) {
+    acc[m] = vy_wave_sum(acc[m]);
+    if constexpr (GATED) acc2[m] = vy_wave_sum(acc2[m]);
+  }
   if (lane < M && lane < MR) {
-    float x = 0.f;
+    float x = 0.f, x2 = 0.f;
 #pragma unroll
-    for (int m = 0; m < MR; ++m) x = lane == m ? acc[m] : x;
+    for (int m = 0; m < MR; ++m) { x = lane == m ? acc[m] : x; x2 = lane == m ? acc2[m] : x2; }
     const int64_t m = lane;
-    if constexpr (EPI == 0) {
+    if constexpr (GATED) {
+      const float gte = vy_round_bf16(x), up = vy_round_bf16(x2);
+      x = vy_act_fwd<ACT>(gte) * up;
+      if (ep.residual) x += (float)ep.residual[m * ep.ldr + n];
+      ep.y[m * ep.ldy + n] = (bf16)x;
+    } else if constexpr (EPI == 0) {
       if (ep.bias) x += (float)ep.bias[n];
       if (ep.pre) ep.pre[m * ep.ldy + n] = (bf16)x;
       x = vy_act_fwd<ACT>(x);
@@ -1979,7 +2023,7 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
       ((uintptr_t)X % 16 == 0) && ((uintptr_t)W % 16 == 0)) {
     if constexpr (!GRAD && (EPI == 1 ? ACT == 0 : true))
       hipLaunchKernelGGL((gemv_bf16_kernel<EPI, ACT, 4>), dim3((unsigned)vy_cdiv(N, 4)), dim3(256), 0, st, X, ldx, W, ldw,
-                         (int)M, (int)N, (int)K, ep, eq);
+                         (int)M, (int)N, (int)K, ep, eq, (const bf16*)nullptr, 0.f);
   } else if (M <= 32 && K % 32 == 0 && !GRAD && N % 16 == 0 && N / 32 < 200 && skinny16_on &&
              (EPI == 0 || !eq.rope || (N % 64 == 0 && eq.dh == 64))) {
     // few 32-column workgroups: 16-column ones, so that twice as many CUs stream weights
@@ -2318,6 +2362,67 @@ int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t l
   else FIN_GO(16);
 #undef FIN_GO
   VY_CHECK_LAUNCH(who);
+  return VY_OK;
+}
+
+// Single-sequence (M <= 4) bf16 projections with the RMSNorm of their input fused in (internal: the Gemma decode
+// driver).  norm_w NULL = no norm.  vy_gemv_gated: w = packed [gate; up] ([2 I, K]) -> y[M, I] = act(gate) * up.
+static bool gemv_ok(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int64_t K) {
+  return M >= 1 && M <= 4 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0);
+}
+int vy_gemv_norm(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, const void* norm_w, float eps,
+                 const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int64_t N, int64_t K, void* stream) {
+  if (!gemv_ok(x, ldx, w, ldw, M, K) || !x || !w || !y) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_gemv_norm: needs M <= 4 and 16-byte aligned rows");
+  EpiPlain<bf16> ep{};
+  ep.bias = (const bf16*)bias; ep.residual = (const bf16*)residual; ep.ldr = ldr; ep.y = (bf16*)y; ep.ldy = ldy;
+  EpiQkv<bf16> eq{};
+  const dim3 grid((unsigned)vy_cdiv(N, 4)), block(256);
+  if (norm_w)
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_NONE, 4, true, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)M, (int)N, (int)K, ep, eq, (const bf16*)norm_w, eps);
+  else
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_NONE, 4, false, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)M, (int)N, (int)K, ep, eq, (const bf16*)nullptr, 0.f);
+  VY_CHECK_LAUNCH("vy_gemv_norm");
+  return VY_OK;
+}
+int vy_gemv_qkv_norm(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, const void* norm_w, float eps,
+                     void* q, int64_t q_sb, int64_t q_sh, void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl, void* v,
+                     int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t K, int h, int hk, int dh, void* stream) {
+  // packed [q | k | v] projection of single-token rows (L = 1), no rotary (applied by vy_rope_qk afterwards)
+  if (!gemv_ok(x, ldx, w, ldw, B, K)) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_gemv_qkv_norm: needs B <= 4 and 16-byte aligned rows");
+  EpiPlain<bf16> ep{};
+  EpiQkv<bf16> eq{};
+  eq.bias = (const bf16*)bias; eq.q = (bf16*)q; eq.q_sb = q_sb; eq.q_sh = q_sh; eq.q_sl = (int64_t)h * dh;
+  eq.k = (bf16*)k; eq.k_sb = k_sb; eq.k_sh = k_sh; eq.k_sl = k_sl;
+  eq.v = (bf16*)v; eq.v_sb = v_sb; eq.v_sh = v_sh; eq.v_sl = v_sl;
+  eq.L = 1; eq.nq = h * dh; eq.nkv = hk * dh; eq.dh = dh; eq.rope = 0; eq.vec8 = 0; eq.pos_dev = nullptr;
+  const int64_t N = (int64_t)(h + 2 * hk) * dh;
+  const dim3 grid((unsigned)vy_cdiv(N, 4)), block(256);
+  if (norm_w)
+    hipLaunchKernelGGL((gemv_bf16_kernel<1, VY_ACT_NONE, 4, true, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)B, (int)N, (int)K, ep, eq, (const bf16*)norm_w, eps);
+  else
+    hipLaunchKernelGGL((gemv_bf16_kernel<1, VY_ACT_NONE, 4, false, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)B, (int)N, (int)K, ep, eq, (const bf16*)nullptr, 0.f);
+  VY_CHECK_LAUNCH("vy_gemv_qkv_norm");
+  return VY_OK;
+}
+int vy_gemv_gated(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* norm_w, float eps, void* y, int64_t ldy,
+                  int64_t M, int64_t I, int64_t K, int act, void* stream) {
+  if (!gemv_ok(x, ldx, w, ldw, M, K)) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_gemv_gated: needs M <= 4 and 16-byte aligned rows");
+  if (act != VY_ACT_GELU_TANH) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_gemv_gated: gelu_tanh only");
+  EpiPlain<bf16> ep{};
+  ep.y = (bf16*)y; ep.ldy = ldy;
+  EpiQkv<bf16> eq{};
+  const dim3 grid((unsigned)vy_cdiv(I, 4)), block(256);
+  if (norm_w)
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_GELU_TANH, 4, true, true>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)M, (int)I, (int)K, ep, eq, (const bf16*)norm_w, eps);
+  else
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_GELU_TANH, 4, false, true>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)M, (int)I, (int)K, ep, eq, (const bf16*)nullptr, 0.f);
+  VY_CHECK_LAUNCH("vy_gemv_gated");
   return VY_OK;
 }
 
