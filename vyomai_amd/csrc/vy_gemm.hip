@@ -74,6 +74,7 @@ struct EpiPlain {
   T* pre; // same ld as y
   int vec_ok;  // all row strides % 4 == 0 and base pointers 4-element aligned
   VyDrop drop; // dropout on act(x W^T + b) before the residual add (thr == 0: none)
+  int wt_store; // large outputs: write-through (sc1) stores from the staged epilogue
 };
 
 template <typename T, int ACT, bool GRAD>
@@ -242,6 +243,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Tile of workgroup `bid`.  Wide launches (>= 8 column tiles): the tile space is cut into 2 column bands x 4 row
+// panel groups, one (band, group) per XCD.  With the plain contiguous run an XCD walks ALL column tiles of its
+// row panels, i.e. streams the whole weight matrix once per "wave" of 32 tiles -- FFN1 (W = 4.7 MB > the 4 MiB
+// L2): 113 MB of weight re-fetch per launch against 30 MB of algorithmic reads (PMC, profiles/r01_gemm_pmc.json).
+// Here an XCD keeps ONE band of W (half the matrix) in its L2 for the whole launch and streams its row panels
+// past it; every X panel is read by two XCDs instead of one: fetch ~ 2 X + 8 * W/2 = 69 MB instead of 138 MB.
+__device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_n, int band_on, int& tile_m, int& tile_n) {
+  const int tiles_m = nwg / tiles_n;
+  if (band_on && tiles_n >= 8 && (tiles_n & 1) == 0 && (tiles_m & 3) == 0 && tiles_m * tiles_n == nwg) {
+    const int xcd = bid & 7, i = bid >> 3;
+    const int band = xcd & 1, grp = xcd >> 1;
+    const int bw = tiles_n >> 1, pg = tiles_m >> 2;
+    tile_m = grp * pg + i / bw;
+    tile_n = band * bw + i - (i / bw) * bw;
+  } else {
+    const int wg = xcd_remap(bid, nwg);
+    tile_m = wg / tiles_n;
+    tile_n = wg - tile_m * tiles_n;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------
@@ -351,7 +373,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
-          *reinterpret_cast<bf16x8*>(dst + m * ep.ldy + n) = o;
+          if (ep.wt_store) {
+            // write-through store (sc1): the line does not stay in this XCD's L2, where a 25-100 MB output stream
+            // would evict the operand panels the XCD's other tiles are reading (MI355X_MICROARCH.md, store flavours)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + m * ep.ldy + n), "v"(o) : "memory");
+          } else {
+            *reinterpret_cast<bf16x8*>(dst + m * ep.ldy + n) = o;
+          }
         } else {
           for (int e = 0; e < 8 && n + e < N; ++e) {
             float x = v[e];
@@ -475,8 +503,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  int tile_m, tile_n;
+  tile_of(blockIdx.x, gridDim.x, tiles_n, !(rot_on & 32), tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-lane LDS-DMA source pointers (row clamped for M/N tails, chunk pre-swizzled) ----
@@ -640,8 +668,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  int tile_m, tile_n;
+  tile_of(blockIdx.x, gridDim.x, tiles_n, !(knob & 32), tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int lrow = lane >> 3, slot = lane & 7;
@@ -869,8 +897,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pipe_kernel(
   };
 
   for (int b = blockIdx.x; b < tiles_total; b += gridDim.x) {
-    const int wg = xcd_remap(b, tiles_total);
-    const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+    int tile_m, tile_n;
+    tile_of(b, tiles_total, tiles_n, !(knob & 32), tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16* xsrc[GX];
     const bf16* wsrc[GW];
@@ -2067,7 +2095,8 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     if constexpr (EPI == 0 && !GRAD) {
       const int64_t tiles = (M / 256) * (N / 192);
       if ((var == 14 || var == 30) && pipe_on && M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && K >= 768 &&
-          tiles >= 2 * 256 && !ep.residual && !ep.residual2 && !ep.drop.thr && ep.vec_ok && !ep.pre) {
+          tiles >= 2 * 256 && !ep.residual && !ep.residual2 && !ep.drop.thr && ep.vec_ok && !ep.pre &&
+          (N < 3072 || var == 30)) {   // (N >= 3072 keeps the 256 x 256 tiles: fewer operand bytes per FLOP)
         static const int pipe_knob = [] { const char* e = getenv("VY_GEMM_PIPE_KNOB"); return e ? atoi(e) : 0; }();
         const int g = (int)(tiles < 256 ? tiles : 256);
         hipLaunchKernelGGL((gemm_nt_bf16_pipe_kernel<ACT>), dim3(g), dim3(512), 0, st, X, ldx, W, ldw, (int)M, (int)N,
@@ -2168,6 +2197,8 @@ int linear_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const vo
   if (residual2 && !residual) VY_FAIL(VY_ERR_ARG, "%s: add_to2 without add_to", who);
   ep.gradpre = (const T*)gradpre; ep.ldg = ldg; ep.y = (T*)y; ep.ldy = ldy; ep.pre = (T*)pre_out;
   ep.drop = drop;
+  static const int wt_env = [] { const char* e = getenv("VY_GEMM_WT_STORE"); return e ? atoi(e) : 1; }();
+  ep.wt_store = (wt_env && (int64_t)M * N * (int64_t)sizeof(T) >= (16 << 20)) ? 1 : 0;
   const int ve = 16 / (int)sizeof(T);  // elements per 16-byte access (bf16: 8, f32 quads: 4)
   ep.vec_ok = (ldy % ve == 0) && aligned_to(y, 16) && (!bias || aligned_to(bias, 4 * sizeof(T))) &&
               (!residual || (ldr % ve == 0 && aligned_to(residual, 16))) &&
