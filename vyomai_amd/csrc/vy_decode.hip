@@ -1,0 +1,515 @@
+// Decode-step kernels (bf16, <= 32 sequences, one new token each): the projections, the split-K finish +
+// LayerNorm, and single-query attention of reference models/decoder.py:430-514 (generate with a KV cache),
+// written for the one thing that bounds a decode step of a d = 768 model on this chip: the LENGTH OF THE
+// DEPENDENT CHAIN inside each launch.
+//
+// Measured (tools/bench_decode_links.py, tools/probe/cold_chain_probe.hip, hipGraph chains): a launch that
+// returns at once costs 1.6 us as a chain link; one that streams 24 KiB per workgroup of never-touched memory,
+// reduces through LDS and stores costs 2.7 us; the general M <= 32 GEMM kernels of vy_gemm.hip cost 4.3-6.7 us on
+// the same shapes.  Their ISA shows why: kernel arguments fetched in three dependent stages, the epilogue operand
+// prefetch retired with vmcnt(0) at a loop header BEFORE the weight loads are issued, a fragment re-loaded and
+// waited for in the middle of the MFMA chain, 64-bit divisions in the scatter addressing.  Each is one more
+// memory round trip (0.3-1 us) in a kernel that is nothing but round trips.  The kernels here have
+//   * no loops around memory instructions (the k-steps of a wave are a compile-time count: every load of the
+//     launch is issued before the first wait, and hipcc can count its waits instead of draining at a loop header),
+//   * one small argument block, no debug knobs, no divisions, the decode case only (one token per row),
+//   * wave reductions on the DPP / permlane path instead of ds_bpermute.
+// Numerics are those of the general kernels (same k order per wave, same combine order, same rounding points), so
+// eager / graph / prefill comparisons in the tests hold unchanged.
+#include "vy_common.h"
+#include <stdlib.h>
+
+namespace {
+
+enum { DEC_STORE = 0, DEC_PART = 1, DEC_QKV = 2 };
+
+// measurement aid (vy_debug_set_decode_stamps, tools/decode_timeline.py): lane 0 of every workgroup's wave 0 writes
+// the 100 MHz wall clock (s_memrealtime) at five points of the kernel into stamps[launch][workgroup][8]
+struct DecDbg { unsigned long long* buf; int slot; int max_wg; };
+#define DEC_STAMP(i)                                                                                          \
+  if constexpr (DBG) { __builtin_amdgcn_sched_barrier(0); dbg_t[i] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
+#define DEC_STAMP_FLUSH()                                                                                     \
+  if constexpr (DBG) {                                                                                        \
+    if (threadIdx.x == 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) < dbg.max_wg) {                        \
+      for (int i_ = 0; i_ < 8; ++i_)                                                                          \
+        dbg.buf[((long long)dbg.slot * dbg.max_wg + blockIdx.x + gridDim.x * blockIdx.y) * 8 + i_] = dbg_t[i_]; \
+    }                                                                                                         \
+  }
+
+struct DecGemmArgs {
+  const bf16* X; const bf16* W; const bf16* bias;
+  int ldx, ldw, M, N;
+  bf16* y; int ldy;                    // DEC_STORE: y[M][ldy] = act(x W^T + b)
+  float* part;                         // DEC_PART: part[gridDim.y][32][N] (fp32, no bias)
+  bf16* q; bf16* k; bf16* v;           // DEC_QKV: q[M][nq]; k / v = cache base (already at the host position)
+  long long c_sb, c_sh, c_sl;          //   element strides of the caches (batch, head, token)
+  const float* cos_tab; const float* sin_tab; const int* pos_dev;
+  int pos0, nq, nkv, rope;
+  int wt;                              // write-through stores
+};
+
+// sum over the 64 lanes, result in every lane: four DPP rotations inside each row of 16 lanes, then the two
+// half-swaps (v_permlane16_swap, v_permlane32_swap) -- six VALU instructions, no LDS round trips
+__device__ __forceinline__ float dec_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+__device__ __forceinline__ float dec_wave_sum(float v) {
+  v = dec_row16_sum(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
+  const unsigned w = __builtin_bit_cast(unsigned, v);
+  auto s32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __builtin_bit_cast(float, (unsigned)s32[0]) + __builtin_bit_cast(float, (unsigned)s32[1]);
+}
+__device__ __forceinline__ float dec_row16_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)));
+  return v;
+}
+__device__ __forceinline__ float dec_wave_max(float v) {
+  v = dec_row16_max(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+  const unsigned w = __builtin_bit_cast(unsigned, v);
+  auto s32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+}
+
+// stores of the step's small outputs.  wt: write-through (sc0 sc1) -- the line does not stay dirty in this XCD's L2,
+// so the write-back at the end of the kernel (every launch boundary releases at agent scope) finds nothing to do
+template <typename V>
+__device__ __forceinline__ void dec_store(void* p, const V& v, int wt) {
+  if (wt) {
+    if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  } else {
+    *reinterpret_cast<V*>(p) = v;
+  }
+}
+
+// the value of lane ^ 32 (v_permlane32_swap instead of a ds_bpermute round trip); upper = this lane is >= 32
+__device__ __forceinline__ float dec_swap32(float v, bool upper) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // s[0] = {lo, lo}, s[1] = {hi, hi}
+  return __builtin_bit_cast(float, upper ? (unsigned)s[0] : (unsigned)s[1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// 16 output columns x 32 rows per workgroup, the K range of the workgroup (4 * U k-steps of 32) split over the
+// 4 waves: wave w takes k-steps w, w + 4, ... -- the four waves together read whole 128-byte lines of every
+// weight row.  mfma_f32_16x16x32_bf16 with A = 16 weight rows, B = 16 batch rows (two row blocks); D[n][m]: a
+// lane owns batch row lane & 15 (and + 16) and the 4 consecutive columns 4 * (lane >> 4) .. + 3.  With fused RoPE
+// a workgroup takes columns {d0 .. d0+7} and {d0+32 .. d0+39} of one 64-wide head: a rotary pair sits in lanes l
+// and l ^ 32.  Same arithmetic as gemm_skinny16_bf16_kernel (vy_gemm.hip).
+// ------------------------------------------------------------------------------------------
+template <int EPI, int ACT, int U, bool DBG>
+__global__ __launch_bounds__(256) void dec_gemm16_kernel(const DecGemmArgs p, const DecDbg dbg) {
+  __shared__ float red[3][8][64];
+  unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  DEC_STAMP(0)
+  if constexpr (DBG) { asm volatile("" ::"s"(p.M), "s"(p.ldw)); }
+  DEC_STAMP(5)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int nb = blockIdx.x;
+  const bool rope_map = EPI == DEC_QKV && p.rope;
+  int col = nb * 16 + r16;
+  if (rope_map) col = (nb >> 2) * 64 + (nb & 3) * 8 + (r16 < 8 ? r16 : 24 + r16);
+  const int m0 = r16 < p.M ? r16 : p.M - 1, m1 = 16 + r16 < p.M ? 16 + r16 : p.M - 1;
+  const int kbase = ((int)blockIdx.y * 4 * U + wave) * 32 + kq * 8;
+  const bf16* wp = p.W + (long long)col * p.ldw + kbase;
+  const bf16* xp0 = p.X + (long long)m0 * p.ldx + kbase;
+  const bf16* xp1 = p.X + (long long)m1 * p.ldx + kbase;
+  if constexpr (DBG) { asm volatile("" ::"v"(wp), "v"(xp0), "v"(xp1)); }
+  DEC_STAMP(6)
+  // this lane's output quad: columns nq0 .. nq0 + 3
+  const int nq0 = rope_map ? (nb >> 2) * 64 + (nb & 3) * 8 + 4 * (kq & 1) + (kq >= 2 ? 32 : 0) : nb * 16 + 4 * kq;
+
+  // every load of the launch, oldest first: bias, the weight / activation fragments, then what depends on the
+  // position (read on the device under a graph)
+  bf16x4 bias4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  if (EPI != DEC_PART && p.bias) bias4 = *reinterpret_cast<const bf16x4*>(p.bias + nq0);
+  bf16x8 a[U], b0[U], b1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    a[u] = *reinterpret_cast<const bf16x8*>(wp + 128 * u);
+    b0[u] = *reinterpret_cast<const bf16x8*>(xp0 + 128 * u);
+    b1[u] = *reinterpret_cast<const bf16x8*>(xp1 + 128 * u);
+  }
+  int pos = 0;
+  f32x4 cos4 = {1.f, 1.f, 1.f, 1.f}, sin4 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == DEC_QKV) {
+    pos = p.pos_dev ? *p.pos_dev : 0;   // (the host position is already in the cache pointers)
+    if (rope_map) {
+      const int dcol = (nb & 3) * 8 + 4 * (kq & 1);
+      const long long pp = (long long)(p.pos0 + pos) * 32 + dcol;
+      cos4 = *reinterpret_cast<const f32x4*>(p.cos_tab + pp);
+      sin4 = *reinterpret_cast<const f32x4*>(p.sin_tab + pp);
+    }
+  }
+  DEC_STAMP(1)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b0[u], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b1[u], acc1, 0, 0, 0);
+  }
+  if constexpr (DBG) { asm volatile("" :: "v"(acc0), "v"(acc1)); }
+  DEC_STAMP(2)
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[wave - 1][r][lane] = acc0[r]; red[wave - 1][4 + r][lane] = acc1[r]; }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  DEC_STAMP(3)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    acc0[r] += red[0][r][lane] + red[1][r][lane] + red[2][r][lane];
+    acc1[r] += red[0][4 + r][lane] + red[1][4 + r][lane] + red[2][4 + r][lane];
+  }
+  if constexpr (EPI == DEC_PART) {
+    float* dst = p.part + ((long long)blockIdx.y * 32 + r16) * p.N + nq0;
+    if (r16 < p.M) dec_store(dst, acc0, p.wt);
+    if (16 + r16 < p.M) dec_store(dst + 16ll * p.N, acc1, p.wt);
+  } else if constexpr (EPI == DEC_STORE) {
+    bf16x4 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o0[i] = (bf16)vy_act_fwd_fast<ACT>(acc0[i] + (float)bias4[i]);
+      o1[i] = (bf16)vy_act_fwd_fast<ACT>(acc1[i] + (float)bias4[i]);
+    }
+    bf16* dst = p.y + (long long)r16 * p.ldy + nq0;
+    if (r16 < p.M) dec_store(dst, o0, p.wt);
+    if (16 + r16 < p.M) dec_store(dst + 16ll * p.ldy, o1, p.wt);
+  } else {
+    // head and offset inside the head of this lane's quad; section q / k / v is workgroup-uniform
+    const int hd = nb >> 2;                       // 64-wide heads: 4 workgroups per head under either column map
+    const int dcol = nq0 & 63;
+    const int hq = p.nq >> 6, hkv = p.nkv >> 6;
+    float v0[4], v1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v0[i] = acc0[i] + (float)bias4[i]; v1[i] = acc1[i] + (float)bias4[i]; }
+    if (rope_map && hd < hq + hkv) {
+      // reference op order (layers/positional_embeddings.py:173-181), every product rounded to bf16; the other
+      // half of each rotary pair is in lane ^ 32
+      const bool hi_half = kq >= 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float c = vy_round_bf16(cos4[i]), sn = vy_round_bf16(sin4[i]);
+        const float o0 = dec_swap32(v0[i], hi_half), o1 = dec_swap32(v1[i], hi_half);
+        const float a0 = vy_round_bf16(v0[i]), a1 = vy_round_bf16(v1[i]);
+        const float t0 = vy_round_bf16(vy_round_bf16(o0) * sn), t1 = vy_round_bf16(vy_round_bf16(o1) * sn);
+        v0[i] = hi_half ? vy_round_bf16(a0 * c) + t0 : vy_round_bf16(a0 * c) - t0;
+        v1[i] = hi_half ? vy_round_bf16(a1 * c) + t1 : vy_round_bf16(a1 * c) - t1;
+      }
+    }
+    bf16x4 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o0[i] = (bf16)v0[i]; o1[i] = (bf16)v1[i]; }
+    bf16* base; long long rs;   // destination of row 0 and the row stride
+    if (hd < hq) { base = p.q + hd * 64 + dcol; rs = p.nq; }
+    else if (hd < hq + hkv) { base = p.k + (hd - hq) * p.c_sh + (long long)pos * p.c_sl + dcol; rs = p.c_sb; }
+    else { base = p.v + (hd - hq - hkv) * p.c_sh + (long long)pos * p.c_sl + dcol; rs = p.c_sb; }
+    if (r16 < p.M) dec_store(base + r16 * rs, o0, p.wt);
+    if (16 + r16 < p.M) dec_store(base + (16 + r16) * rs, o1, p.wt);
+  }
+  if constexpr (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  DEC_STAMP(4)
+  DEC_STAMP_FLUSH()
+}
+
+// ------------------------------------------------------------------------------------------
+// Partial tiles of the two N = d projections (out-projection, FFN2) for the split-K finish below: 64 output
+// columns x 32 rows x a SHORT K range (U k-steps of 32) per workgroup, one 16-column block per WAVE, all four
+// waves on the same K range.  The timeline (tools/decode_timeline.py) shows what a launch of dec_gemm16_kernel
+// waits for: its 73 KB per workgroup (49 KB of it the activations, re-read by every workgroup) arrive at the
+// ~30 GB/s one CU takes in -- 2.4 us.  Bytes per workgroup for a (c columns, k range) tile are 2k(32 + c) against
+// k c of work: wide and short is cheapest, and costs nothing here because these projections are split over K
+// anyway.  12 KB of activations (shared by the four waves through L1) + 24 KB of weights per workgroup, no
+// cross-wave reduction, no LDS, no barrier.  part[gridDim.y][32][N] as in dec_gemm16_kernel<DEC_PART>.
+// ------------------------------------------------------------------------------------------
+template <int U, bool DBG>
+__global__ __launch_bounds__(256) void dec_gemm64p_kernel(const DecGemmArgs p, const DecDbg dbg) {
+  unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  DEC_STAMP(0)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int col = (int)blockIdx.x * 64 + wave * 16 + r16;
+  const int m0 = r16 < p.M ? r16 : p.M - 1, m1 = 16 + r16 < p.M ? 16 + r16 : p.M - 1;
+  const int kbase = (int)blockIdx.y * U * 32 + kq * 8;
+  const bf16* wp = p.W + (long long)col * p.ldw + kbase;
+  const bf16* xp0 = p.X + (long long)m0 * p.ldx + kbase;
+  const bf16* xp1 = p.X + (long long)m1 * p.ldx + kbase;
+  bf16x8 a[U], b0[U], b1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    a[u] = *reinterpret_cast<const bf16x8*>(wp + 32 * u);
+    b0[u] = *reinterpret_cast<const bf16x8*>(xp0 + 32 * u);
+    b1[u] = *reinterpret_cast<const bf16x8*>(xp1 + 32 * u);
+  }
+  DEC_STAMP(1)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b0[u], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b1[u], acc1, 0, 0, 0);
+  }
+  if constexpr (DBG) { asm volatile("" :: "v"(acc0), "v"(acc1)); }
+  DEC_STAMP(2)
+  float* dst = p.part + ((long long)blockIdx.y * 32 + r16) * p.N + (int)blockIdx.x * 64 + wave * 16 + 4 * kq;
+  if (r16 < p.M) dec_store(dst, acc0, p.wt);
+  if (16 + r16 < p.M) dec_store(dst + 16ll * p.N, acc1, p.wt);
+  if constexpr (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  DEC_STAMP(4)
+  DEC_STAMP_FLUSH()
+}
+
+// ------------------------------------------------------------------------------------------
+// y = LayerNorm(bf16(act(sum_k part[k] + bias) + residual)), ONE WORKGROUP PER ROW: every thread requests its
+// 4 columns of every partial tile, bias, residual, gamma and beta at once (one memory round trip), then two
+// block reductions (the arithmetic of splitk_finish_ln_row_kernel, vy_gemm.hip).
+// ------------------------------------------------------------------------------------------
+template <int KS, int QPT, int ACT, bool DBG>
+__global__ __launch_bounds__(256) void dec_finish_ln_kernel(const float* __restrict__ part, int ksplit, int N,
+                                                            const bf16* __restrict__ bias,
+                                                            const bf16* __restrict__ residual, int ldr,
+                                                            const bf16* __restrict__ gamma,
+                                                            const bf16* __restrict__ beta, bf16* __restrict__ y,
+                                                            int ldy, float eps, int wt, const DecDbg dbg) {
+  __shared__ float red[2][4];
+  unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  DEC_STAMP(0)
+  if constexpr (DBG) { asm volatile("" ::"s"(N), "s"(ksplit)); }
+  DEC_STAMP(5)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x;
+  const int nq = N >> 2;
+  f32x4 pk[QPT][KS];
+  bf16x4 b4[QPT], r4[QPT], g4[QPT], be4[QPT];
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + 256 * i;
+    const int n = (q < nq ? q : 0) * 4;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+      pk[i][k] = *reinterpret_cast<const f32x4*>(part + ((long long)(k < ksplit ? k : 0) * 32 + row) * N + n);
+    b4[i] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    r4[i] = b4[i];
+    if (bias) b4[i] = *reinterpret_cast<const bf16x4*>(bias + n);
+    if (residual) r4[i] = *reinterpret_cast<const bf16x4*>(residual + (long long)row * ldr + n);
+    g4[i] = *reinterpret_cast<const bf16x4*>(gamma + n);
+    be4[i] = *reinterpret_cast<const bf16x4*>(beta + n);
+  }
+  DEC_STAMP(1)
+  float v[QPT][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const bool ok = tid + 256 * i < nq;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k < ksplit) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += pk[i][k][e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] += (float)b4[i][e];
+      if constexpr (ACT != VY_ACT_NONE) a[e] = vy_act_fwd_fast<ACT>(a[e]);
+      a[e] += (float)r4[i][e];
+      v[i][e] = ok ? vy_round_bf16(a[e]) : 0.f;
+      s += v[i][e];
+    }
+  }
+  DEC_STAMP(2)
+  s = dec_wave_sum(s);
+  if (lane == 0) red[0][wave] = s;
+  __syncthreads();
+  const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)N;
+  float qv = 0.f;
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    if (tid + 256 * i < nq) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; qv += d * d; }
+    }
+  }
+  qv = dec_wave_sum(qv);
+  if (lane == 0) red[1][wave] = qv;
+  __syncthreads();
+  DEC_STAMP(3)
+  const float var = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)N;
+  const float rstd = rsqrtf(var + eps);
+  const float rstd_r = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+#pragma unroll
+  for (int i = 0; i < QPT; ++i) {
+    const int q = tid + 256 * i;
+    if (q < nq) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[i][e] - mean) * rstd_r * (float)g4[i][e] + (float)be4[i][e]);
+      dec_store(y + (long long)row * ldy + q * 4, o, wt);
+    }
+  }
+  if constexpr (DBG) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  DEC_STAMP(4)
+  DEC_STAMP_FLUSH()
+}
+
+DecDbg g_dbg{nullptr, 0, 0};
+int g_dbg_launches = 0;
+
+int dec_wt() {
+  static const int v = [] { const char* e = getenv("VY_DEC_WT"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
+template <int EPI, int ACT>
+int dec_gemm_go(DecGemmArgs a, int K, int chunks, hipStream_t st) {
+  a.wt = dec_wt();
+  const int u4 = K / chunks / 128;   // k-steps per wave
+  const dim3 grid((unsigned)(a.N / 16), (unsigned)chunks), block(256);
+  if (g_dbg.buf && g_dbg.slot < g_dbg_launches) {
+    if (u4 == 6) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 6, true>), grid, block, 0, st, a, g_dbg);
+    else if (u4 == 8) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 8, true>), grid, block, 0, st, a, g_dbg);
+    else if (u4 == 4) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 4, true>), grid, block, 0, st, a, g_dbg);
+    else return 1;
+    ++g_dbg.slot;
+    return 0;
+  }
+  if (u4 == 6) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 6, false>), grid, block, 0, st, a, g_dbg);
+  else if (u4 == 8) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 8, false>), grid, block, 0, st, a, g_dbg);
+  else if (u4 == 4) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 4, false>), grid, block, 0, st, a, g_dbg);
+  else return 1;
+  return 0;
+}
+
+// partial tiles with 64-column workgroups: k-steps per workgroup U in {6, 8, 4}; returns the number of K chunks or 0
+int dec_part64_go(DecGemmArgs a, int K, hipStream_t st) {
+  a.wt = dec_wt();
+  int u = 0;
+  for (int c : {6, 8, 4})
+    if (K % (32 * c) == 0 && K / (32 * c) <= 24) { u = c; break; }
+  if (!u || a.N % 64) return 0;
+  const int chunks = K / (32 * u);
+  const dim3 grid((unsigned)(a.N / 64), (unsigned)chunks), block(256);
+  const bool dbg_on = g_dbg.buf && g_dbg.slot < g_dbg_launches;
+#define P64(UU)                                                                                   \
+  do {                                                                                            \
+    if (dbg_on) hipLaunchKernelGGL((dec_gemm64p_kernel<UU, true>), grid, block, 0, st, a, g_dbg);  \
+    else hipLaunchKernelGGL((dec_gemm64p_kernel<UU, false>), grid, block, 0, st, a, g_dbg);        \
+  } while (0)
+  if (u == 6) P64(6); else if (u == 8) P64(8); else P64(4);
+#undef P64
+  if (dbg_on) ++g_dbg.slot;
+  return chunks;
+}
+
+}  // namespace
+
+// K ranges a workgroup of dec_gemm16_kernel can take: 4 waves x {4, 6, 8} k-steps of 32
+static int dec_chunks(int64_t K, bool may_split) {
+  for (int u : {6, 8, 4}) {
+    const int64_t c = 128 * u;
+    if (K % c == 0 && (K == c || (may_split && K / c <= 12))) return (int)(K / c);
+  }
+  return 0;
+}
+
+// can the lean kernels run a model of these sizes?  (bf16, <= 32 rows, 64-wide heads, the K of every projection a
+// chunk size the straight-line kernels exist for; otherwise the decode driver keeps the general launchers)
+bool vy_dec_supported(int B, int d, int h, int hk, int dh, int ffn, int dtype) {
+  return dtype == VY_BF16 && B >= 1 && B <= 32 && dh == 64 && h * dh == d && d % 16 == 0 && d % 4 == 0 && d <= 8192 && ffn % 16 == 0 &&
+         (h + 2 * hk) * dh % 16 == 0 && dec_chunks(d, false) == 1 && dec_chunks(ffn, true) > 0;
+}
+
+int vy_dec_qkv(const void* x, const void* w, const void* bias, const float* cos_tab, const float* sin_tab, int64_t pos0,
+               const int* pos_dev, void* q, void* k, void* v, int64_t c_sb, int64_t c_sh, int64_t c_sl, int B, int d, int h,
+               int hk, hipStream_t st) {
+  DecGemmArgs a{};
+  a.X = (const bf16*)x; a.W = (const bf16*)w; a.bias = (const bf16*)bias;
+  a.ldx = d; a.ldw = d; a.M = B; a.N = (h + 2 * hk) * 64;
+  a.q = (bf16*)q; a.k = (bf16*)k; a.v = (bf16*)v; a.c_sb = c_sb; a.c_sh = c_sh; a.c_sl = c_sl;
+  a.cos_tab = cos_tab; a.sin_tab = sin_tab; a.pos_dev = pos_dev; a.pos0 = pos_dev ? 0 : (int)pos0;
+  a.nq = h * 64; a.nkv = hk * 64; a.rope = cos_tab != nullptr;
+  if (dec_gemm_go<DEC_QKV, VY_ACT_NONE>(a, d, 1, st)) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_dec_qkv: K = %d", d);
+  VY_CHECK_LAUNCH("vy_dec_qkv");
+  return VY_OK;
+}
+
+// y[B][N] = act(x W^T + b), K one chunk
+int vy_dec_linear(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int N, int K, int act,
+                  hipStream_t st) {
+  DecGemmArgs a{};
+  a.X = (const bf16*)x; a.W = (const bf16*)w; a.bias = (const bf16*)bias;
+  a.ldx = ldx; a.ldw = K; a.M = B; a.N = N; a.y = (bf16*)y; a.ldy = ldy;
+  int rc;
+  if (act == VY_ACT_GELU_ERF) rc = dec_gemm_go<DEC_STORE, VY_ACT_GELU_ERF>(a, K, 1, st);
+  else if (act == VY_ACT_GELU_TANH) rc = dec_gemm_go<DEC_STORE, VY_ACT_GELU_TANH>(a, K, 1, st);
+  else rc = dec_gemm_go<DEC_STORE, VY_ACT_NONE>(a, K, 1, st);
+  if (rc) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_dec_linear: K = %d", K);
+  VY_CHECK_LAUNCH("vy_dec_linear");
+  return VY_OK;
+}
+
+// y = LayerNorm(bf16(act(x W^T + b) + residual)): split-K partial tiles, then one workgroup per row
+int vy_dec_linear_res_ln(const void* x, int ldx, const void* w, const void* bias, const void* residual, int ldr,
+                         const void* gamma, const void* beta, float eps, void* y, int ldy, float* part, int B, int N, int K,
+                         int act, hipStream_t st) {
+  const char* who = "vy_dec_linear_res_ln";
+  if (N % 16 || N % 4 || N > 8192) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: N = %d", who, N);
+  DecGemmArgs a{};
+  a.X = (const bf16*)x; a.W = (const bf16*)w; a.ldx = ldx; a.ldw = K; a.M = B; a.N = N; a.part = part;
+  static const int p64_env = [] { const char* e = getenv("VY_DEC_P64"); return e ? atoi(e) : 1; }();
+  int chunks = p64_env ? dec_part64_go(a, K, st) : 0;
+  if (!chunks) {
+    chunks = dec_chunks(K, true);
+    if (!chunks) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: N = %d, K = %d", who, N, K);
+    if (dec_gemm_go<DEC_PART, VY_ACT_NONE>(a, K, chunks, st)) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: K = %d", who, K);
+  }
+  VY_CHECK_LAUNCH(who);
+  const int qpt = (int)vy_cdiv(N / 4, 256);
+  const bool dbg_on = g_dbg.buf && g_dbg.slot < g_dbg_launches;
+#define FIN(KS, Q, A)                                                                                                  \
+  do {                                                                                                                 \
+    if (dbg_on)                                                                                                        \
+      hipLaunchKernelGGL((dec_finish_ln_kernel<KS, Q, A, true>), dim3((unsigned)B), dim3(256), 0, st, part, chunks, N, \
+                         (const bf16*)bias, (const bf16*)residual, ldr, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, ldy, eps, dec_wt(), g_dbg); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((dec_finish_ln_kernel<KS, Q, A, false>), dim3((unsigned)B), dim3(256), 0, st, part, chunks, N, \
+                         (const bf16*)bias, (const bf16*)residual, ldr, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, ldy, eps, dec_wt(), g_dbg); \
+  } while (0)
+#define FIN_Q(KS, A)                                                                                                   \
+  do { if (qpt <= 1) FIN(KS, 1, A); else if (qpt <= 2) FIN(KS, 2, A); else if (qpt <= 4) FIN(KS, 4, A); else FIN(KS, 8, A); } while (0)
+#define FIN_K(A)                                                                                                       \
+  do { if (chunks <= 1) FIN_Q(1, A); else if (chunks <= 4) FIN_Q(4, A); else if (chunks <= 8) FIN_Q(8, A); else if (chunks <= 16) FIN_Q(16, A); else FIN_Q(24, A); } while (0)
+  if (act == VY_ACT_GELU_ERF) FIN_K(VY_ACT_GELU_ERF);
+  else if (act == VY_ACT_GELU_TANH) FIN_K(VY_ACT_GELU_TANH);
+  else FIN_K(VY_ACT_NONE);
+#undef FIN_K
+#undef FIN_Q
+#undef FIN
+  if (dbg_on) ++g_dbg.slot;
+  VY_CHECK_LAUNCH(who);
+  return VY_OK;
+}
+
+// measurement aid, not part of include/vyom_hip.h: the next `launches` launches of the kernels in this file write
+// their stamps into buf[launches][max_wg][8] (device memory, 64-bit words); buf = NULL switches it off
+extern "C" int vy_debug_set_decode_stamps(void* buf, int launches, int max_wg) {
+  g_dbg.buf = (unsigned long long*)buf; g_dbg.slot = 0; g_dbg.max_wg = max_wg; g_dbg_launches = launches;
+  return 0;
+}

@@ -28,6 +28,21 @@ int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t l
                             const void* residual, int64_t ldr, const void* gamma, const void* beta, float eps,
                             void* y, int64_t ldy, float* part, int64_t M, int64_t N, int64_t K, void* stream);
 
+// lean decode kernels (vy_decode.hip)
+bool vy_dec_supported(int B, int d, int h, int hk, int dh, int ffn, int dtype);
+int vy_dec_qkv(const void* x, const void* w, const void* bias, const float* cos_tab, const float* sin_tab, int64_t pos0,
+               const int* pos_dev, void* q, void* k, void* v, int64_t c_sb, int64_t c_sh, int64_t c_sl, int B, int d, int h,
+               int hk, hipStream_t st);
+int vy_dec_linear(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int N, int K, int act,
+                  hipStream_t st);
+int vy_dec_linear_res_ln(const void* x, int ldx, const void* w, const void* bias, const void* residual, int ldr,
+                         const void* gamma, const void* beta, float eps, void* y, int ldy, float* part, int B, int N, int K,
+                         int act, hipStream_t st);
+
+static int g_decode_lean = -1;
+// measurement / test aid, not part of include/vyom_hip.h: 0 = general launchers, 1 = the decode-only kernels
+extern "C" int vy_debug_set_decode_lean(int v) { g_decode_lean = v; return 0; }
+
 namespace {
 inline int64_t esize(int dtype) { return dtype == VY_BF16 ? 2 : 4; }
 inline int64_t up(int64_t x) { return (x + 255) / 256 * 256; }
@@ -38,7 +53,7 @@ extern "C" int64_t vy_decode_ws_bytes(int32_t B, int32_t d, int32_t h, int32_t h
   const int64_t e = esize(dtype);
   // q, attn out, s (pre-LN), a (post-LN1), mid (ffn), two ping-pong hidden buffers, split-K partials
   return up(B * (int64_t)h * dh * e) + 5 * up(B * (int64_t)d * e) + up(B * (int64_t)ffn * e) +
-         up(vy_splitk_ws_floats(d) * 4) + 4096;
+         up((vy_splitk_ws_floats(d) > 24 * 32 * (int64_t)d ? vy_splitk_ws_floats(d) : 24 * 32 * (int64_t)d) * 4) + 4096;
 }
 
 extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t pos, const int32_t* pos_dev,
@@ -63,6 +78,11 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
   // over ~all CUs, their bias + residual + LayerNorm fused into the kernel that adds the partials
   const bool splitk = p->dtype == VY_BF16 && B <= 32 && d % 32 == 0 && d <= 8192 && p->ffn % 16 == 0;
   const float scale = 1.0f / sqrtf((float)dh);
+  // the decode-only kernels of vy_decode.hip (short dependent chains): bf16, 64-wide heads, K of every projection a
+  // chunk size they exist for (VY_DECODE_LEAN=0: the general launchers, for A/B runs and the equality test)
+  if (g_decode_lean < 0) { const char* e = getenv("VY_DECODE_LEAN"); g_decode_lean = e ? atoi(e) : 1; }
+  const bool lean = g_decode_lean && vy_dec_supported(B, d, h, hk, dh, p->ffn, p->dtype);
+  hipStream_t hst = (hipStream_t)stream;
   const void* cur = x;
   for (int l = 0; l < p->num_layers; ++l) {
     const vy_decode_layer& L = p->layers[l];
@@ -72,6 +92,24 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
     const int64_t hpos = pos_dev ? 0 : pos;
     void* kdst = (char*)L.kcache + hpos * L.c_sl * e;
     void* vdst = (char*)L.vcache + hpos * L.c_sl * e;
+    if (lean) {
+      int rc = vy_dec_qkv(cur, L.wqkv, L.bqkv, p->cos_tab, p->sin_tab, pos, pos_dev, q, kdst, vdst, L.c_sb, L.c_sh, L.c_sl, B,
+                          d, h, hk, hst);
+      if (rc) return rc;
+      rc = vy_attn_decode_ex(q, (int64_t)h * dh, dh, L.kcache, L.c_sb, L.c_sh, L.c_sl, L.vcache, L.c_sb, L.c_sh,
+                             L.c_sl, ao, d, B, h, hk, pos + 1, pos_dev, dh, scale, p->dtype, stream);
+      if (rc) return rc;
+      rc = vy_dec_linear_res_ln(ao, d, L.wo, L.bo, cur, d, L.ln1_w, L.ln1_b, p->eps_attn, a, d, part, B, d, d, VY_ACT_NONE, hst);
+      if (rc) return rc;
+      rc = vy_dec_linear(a, d, L.w1, L.b1, mid, p->ffn, B, p->ffn, d, p->act, hst);
+      if (rc) return rc;
+      void* nxt_l = hb[l & 1];   // FFN residual = the LAYER INPUT (reference models/decoder.py:241-250)
+      rc = vy_dec_linear_res_ln(mid, p->ffn, L.w2, L.b2, cur, d, L.ln2_w, L.ln2_b, p->eps_ffn, nxt_l, d, part, B, d, p->ffn,
+                                VY_ACT_NONE, hst);
+      if (rc) return rc;
+      cur = nxt_l;
+      continue;
+    }
     int rc = vy_qkv_rope_fwd_ex(cur, d, L.wqkv, d, L.bqkv, p->cos_tab, p->sin_tab, pos, pos_dev, q, (int64_t)h * dh,
                                 dh, dh, kdst, L.c_sb, L.c_sh, L.c_sl, vdst, L.c_sb, L.c_sh, L.c_sl, B, 1, d, h, hk,
                                 dh, p->dtype, stream);
@@ -109,11 +147,18 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
       VY_FAIL(VY_ERR_LAUNCH, "%s: copy of the hidden state failed", who);
   }
   if (logits) {
-    int rc = vy_linear_fwd(cur, d, p->head_wd, d, p->head_bd, nullptr, 0, s, d, nullptr, B, d, d, VY_ACT_GELU_ERF,
-                           p->dtype, stream);
-    if (rc) return rc;
-    rc = vy_layernorm_fwd(s, d, p->head_ln_w, p->head_ln_b, a, d, nullptr, nullptr, B, d, p->eps_head, p->dtype, stream);
-    if (rc) return rc;
+    int rc;
+    if (lean) {   // LayerNorm(gelu(dense)) of the LM head: partial tile + finish
+      rc = vy_dec_linear_res_ln(cur, d, p->head_wd, p->head_bd, nullptr, 0, p->head_ln_w, p->head_ln_b, p->eps_head, a, d,
+                                part, B, d, d, VY_ACT_GELU_ERF, hst);
+      if (rc) return rc;
+    } else {
+      rc = vy_linear_fwd(cur, d, p->head_wd, d, p->head_bd, nullptr, 0, s, d, nullptr, B, d, d, VY_ACT_GELU_ERF,
+                         p->dtype, stream);
+      if (rc) return rc;
+      rc = vy_layernorm_fwd(s, d, p->head_ln_w, p->head_ln_b, a, d, nullptr, nullptr, B, d, p->eps_head, p->dtype, stream);
+      if (rc) return rc;
+    }
     rc = vy_linear_fwd(a, d, p->head_wv, d, p->head_bias, nullptr, 0, logits, ldv, nullptr, B, p->vocab, d,
                        VY_ACT_NONE, p->dtype, stream);
     if (rc) return rc;
