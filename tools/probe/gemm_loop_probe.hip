@@ -225,6 +225,134 @@ __global__ __launch_bounds__(PF ? 576 : 512) void kloop(const bf16* __restrict__
   if (tid == 0) clk[blockIdx.x] = t1 - t0;
 }
 
+
+// the same loop with mfma_f32_16x16x32_bf16 (24 per 32-deep k-step, 4 x 6 blocks of 16 x 16 per wave): the chip can hold
+// a higher clock on this shape (MI355X_MICROARCH.md, DVFS give-back item 7); same LDS image, same swizzle
+template <int MODE>
+__global__ __launch_bounds__(512) void kloop16(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+                                               int64_t ldw, int K, int tiles_n, unsigned long long* clk, float* sink) {
+  constexpr int BM = 256, BN = 192, BK = 64, ROWB = 128, NW = 8, WGN = 2;
+  constexpr int TM = 4, TN = 6;
+  constexpr int PX = BM / 8, PW = BN / 8, GX = PX / NW, GW = PW / NW;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr bool LOADS = MODE & 1, READS = MODE & 2, MFMA = MODE & 4;
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int KT = K / BK;
+  const int lrow = lane >> 3, slot = lane & 7;
+  const bf16* xsrc[GX];
+  const bf16* wsrc[GW];
+#pragma unroll
+  for (int t = 0; t < GX; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    xsrc[t] = X + (int64_t)(m0 + R) * ldx + (slot ^ ((R >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    wsrc[t] = W + (int64_t)(n0 + R) * ldw + (slot ^ ((R >> 1) & 7)) * 8;
+  }
+  auto load_stage = [&](int kt) {
+    char* xb = smem + (kt & 1) * STAGE;
+    char* wb = xb + BM * ROWB;
+#pragma unroll
+    for (int pc = 0; pc < GW; ++pc)
+      __builtin_amdgcn_global_load_lds((const GLB void*)(wsrc[pc] + kt * BK), (LDS void*)(wb + (wave + NW * pc) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int pc = 0; pc < GX; ++pc)
+      __builtin_amdgcn_global_load_lds((const GLB void*)(xsrc[pc] + kt * BK), (LDS void*)(xb + (wave + NW * pc) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r16 = lane & 15, kq = lane >> 4, fsw = (r16 >> 1) & 7;
+  unsigned xa[2], wa[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int coff = (((ks * 4 + kq) ^ fsw) << 4);
+    xa[ks] = lds_addr(smem) + (wm * 64 + r16) * ROWB + coff;
+    wa[ks] = lds_addr(smem) + BM * ROWB + (wn * 96 + r16) * ROWB + coff;
+  }
+  bf16x8 wf[2][TN], xf[2][TM];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wf[b][i][e] = (bf16)(float)((lane + e + i) % 7 - 3);
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xf[b][j][e] = (bf16)(float)((lane * 3 + e + j) % 5 - 2);
+  }
+  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    if (!READS) return;
+    w_[0] = lds_read128<0>(wbase);
+    w_[1] = lds_read128<16 * ROWB>(wbase);
+    w_[2] = lds_read128<32 * ROWB>(wbase);
+    w_[3] = lds_read128<48 * ROWB>(wbase);
+    w_[4] = lds_read128<64 * ROWB>(wbase);
+    w_[5] = lds_read128<80 * ROWB>(wbase);
+    x_[0] = lds_read128<0>(xbase);
+    x_[1] = lds_read128<16 * ROWB>(xbase);
+    x_[2] = lds_read128<32 * ROWB>(xbase);
+    x_[3] = lds_read128<48 * ROWB>(xbase);
+  };
+  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) tie(w_[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) tie(x_[j]);
+  };
+  auto mma = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    if (!MFMA) return;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_[i], x_[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (LOADS) load_stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  read_frags(wa[0], xa[0], wf[0], xf[0]);
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;
+    if (LOADS && more) load_stage(kt + 1);
+    const unsigned boff = (kt & 1) * STAGE;
+    // k-step 0 of the stage (fragments already requested), then k-step 1
+    read_frags(wa[1] + boff, xa[1] + boff, wf[1], xf[1]);
+    if (READS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+    tie_frags(wf[0], xf[0]);
+    mma(wf[0], xf[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tie_frags(wf[1], xf[1]);
+    mma(wf[1], xf[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (more) read_frags(wa[0] + (STAGE - boff), xa[0] + (STAGE - boff), wf[0], xf[0]);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) s += acc[i][0][0] + acc[i][1][1] + acc[i][2][2] + acc[i][3][3];
+  if (s == 12345.678f) sink[0] = s;
+  if (tid == 0) clk[blockIdx.x] = t1 - t0;
+}
+
 static const bf16 *dX, *dW;
 static unsigned long long* dclk;
 static float* dsink;
@@ -251,6 +379,25 @@ void run(const char* what) {
          mf / 1024.0, ms * 1e3 / reps, (MODE & 4) ? 2.0 * M * N * K / (ms * 1e-3 / reps) * 1e-12 : 0.0);
 }
 
+template <int MODE>
+void run16(const char* what) {
+  const int BN = 192;
+  const int tiles_n = N / BN, nwg = (M / 256) * tiles_n;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int w = 0; w < 3; ++w) kloop16<MODE><<<nwg, 512>>>(dX, K, dW, K, K, tiles_n, dclk, dsink);
+  (void)hipEventRecord(e0);
+  const int reps = 10;
+  for (int w = 0; w < reps; ++w) kloop16<MODE><<<nwg, 512>>>(dX, K, dW, K, K, tiles_n, dclk, dsink);
+  (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  std::vector<unsigned long long> h(nwg);
+  (void)hipMemcpy(h.data(), dclk, nwg * 8, hipMemcpyDeviceToHost);
+  double cyc = 0; for (int i = 0; i < nwg; ++i) cyc += h[i];
+  cyc /= nwg;
+  printf("K %4d %-58s BN %3d: %7.0f cycles/stage (MFMA alone 1536)  %7.1f us/launch  %6.1f TFLOP/s\n", K, what, BN, cyc / (K / 64),
+         ms * 1e3 / reps, (MODE & 4) ? 2.0 * M * N * K / (ms * 1e-3 / reps) * 1e-12 : 0.0);
+}
+
 int main() {
   std::vector<uint16_t> hx((size_t)M * 3072), hw((size_t)N * 3072);
   unsigned s = 12345;
@@ -260,6 +407,20 @@ int main() {
   (void)hipMalloc(&dclk, 8192 * 8); (void)hipMalloc(&dsink, 64);
   (void)hipMemcpy((void*)dX, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
   (void)hipMemcpy((void*)dW, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+  if (getenv("QUICK")) {
+    for (int rep = 0; rep < 2; ++rep) {
+      run<4, 0, 192>("32x32x16: MFMA only");
+      run16<4>("16x16x32: MFMA only");
+      run<6, 0, 192>("32x32x16: MFMA + reads");
+      run16<6>("16x16x32: MFMA + reads");
+      run<7, 0, 192>("32x32x16: all (two-stage)");
+      run16<7>("16x16x32: all (two-stage)");
+    }
+    K = 768;
+    run<7, 0, 192>("32x32x16: all (two-stage)");
+    run16<7>("16x16x32: all (two-stage)");
+    return 0;
+  }
   run<4, 0, 192>("MFMA only");
   run<2, 0, 192>("fragment reads only");
   run<1, 0, 192>("LDS-DMA loads only (issue, wait, barrier)");

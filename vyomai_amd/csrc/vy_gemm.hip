@@ -146,6 +146,18 @@ struct EpiQkv {
   const int* pos_dev;  // decode under a hipGraph: token position read on the device (else NULL)
 };
 
+// the same for 64-wide heads (the fused-RoPE case): shifts instead of divisions by the runtime head width, and
+// the position added once -- this runs once per 16-byte chunk of a phase that is VALU-bound
+template <typename T>
+__device__ __forceinline__ T* qkv_dest64(const EpiQkv<T>& e, int64_t b, int64_t l, int n, int64_t lkv) {
+  const int d = n & 63;
+  if (n < e.nq) return e.q + b * e.q_sb + (n >> 6) * e.q_sh + l * e.q_sl + d;
+  n -= e.nq;
+  if (n < e.nkv) return e.k + b * e.k_sb + (n >> 6) * e.k_sh + lkv * e.k_sl + d;
+  n -= e.nkv;
+  return e.v + b * e.v_sb + (n >> 6) * e.v_sh + lkv * e.v_sl + d;
+}
+
 template <typename T>
 __device__ __forceinline__ T* qkv_dest(const EpiQkv<T>& e, int64_t b, int64_t l, int n) {
   // n: column in the packed [q | k | v] output; returns pointer to element (b, head, l, d)
@@ -270,10 +282,21 @@ __device__ __forceinline__ void tile_of(int bid, int nwg, int tiles_n, int band_
 constexpr int BK = 64;            // k elements per stage
 constexpr int ROWB = BK * 2;      // bytes per LDS row (128)
 
+// LDS bytes of the staged epilogue: the bf16 tile band (rows padded by 16 B) and, for the QKV epilogue, the
+// rotary table of the band's rows (cos | sin, 32 + 32 bf16 = 128 B per row) when both fit in 160 KiB
+constexpr int epi_tile_bytes(int BM, int BN, int PASSES) { return (BM / PASSES) * (BN * 2 + 16); }
+constexpr bool epi_has_rope_tab(int BM, int BN, int EPI, int PASSES) {
+  return EPI == 1 && epi_tile_bytes(BM, BN, PASSES) + (BM / PASSES) * 128 <= 160 * 1024;
+}
+constexpr int epi_lds_bytes(int BM, int BN, int EPI, int PASSES) {
+  return epi_tile_bytes(BM, BN, PASSES) + (epi_has_rope_tab(BM, BN, EPI, PASSES) ? (BM / PASSES) * 128 : 0);
+}
+constexpr int vy_cmax(int a, int b) { return a > b ? a : b; }
+
 // ---- shared epilogue of the bf16 kernels ------------------------------------------------------
 // PASSES > 1: the staged tile does not fit next to a second resident workgroup's LDS, so it goes out in
 // PASSES row bands of BM / PASSES rows (each band is owned by whole wave rows: WGM % PASSES == 0).
-template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD, int PASSES = 1>
+template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD, int PASSES = 1, bool PF_OK = true>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM / (32 * WGM)], char* smem,
                                               int m0, int n0, int M, int N, const EpiPlain<bf16>& ep,
                                               const EpiQkv<bf16>& eq) {
@@ -321,12 +344,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
     // values -- what the reference's bf16 Linear -> GELU computes -- and, when the caller wants the
     // pre-activation saved for backward (dual), it is stored from the same chunk: one pass over the
     // tile, no second staging pass, no GELU chains among the accumulator registers.
-    auto flush_plain = [&](bf16* __restrict__ dst, bool final_pass, bool dual, int pass) {
-      for (int c = tid; c < RP * CPR; c += NT) {
+    // one 16-byte chunk of the staged band.  pf: the chunk's second operand (residual, or the pre-activation of a
+    // dgrad) was requested BEFORE the accumulators were staged and is handed in as p8 -- loaded here, inside the
+    // loop, every iteration waits a full memory latency for it (the residual epilogue measured 22 k cycles per
+    // tile against 12 k without the residual)
+    const bf16* pf_ptr = GRAD ? (ep.gradpre ? ep.gradpre : ep.residual) : ep.residual;
+    const int64_t pf_ld = GRAD ? (ep.gradpre ? ep.ldg : ep.ldr) : ep.ldr;
+    const bool pf_is_gradpre = GRAD && ep.gradpre != nullptr;
+    auto do_chunk = [&](bf16* __restrict__ dst, bool dual, int pass, int c, bool pf, const bf16x8& p8) {
         const int row = c / CPR, cc = c - row * CPR;
         const int64_t m = m0 + pass * RP + row;
         const int n = n0 + cc * 8;
-        if (m >= M || n >= N) continue;
+        if (m >= M || n >= N) return;
         const bf16x8 sv = *reinterpret_cast<const bf16x8*>(et + row * EROW + cc * 16);
         float v[8];
 #pragma unroll
@@ -351,24 +380,22 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
           }
         }
         if (ep.vec_ok && n + 8 <= N) {
-          if (final_pass) {
-            if constexpr (GRAD) {
-              if (ep.gradpre) {
-                const bf16x8 g = *reinterpret_cast<const bf16x8*>(ep.gradpre + m * ep.ldg + n);
+          if constexpr (GRAD) {
+            if (ep.gradpre) {
+              const bf16x8 g = pf ? p8 : *reinterpret_cast<const bf16x8*>(ep.gradpre + m * ep.ldg + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= vy_act_grad_fast<ACT>((float)g[e]);
-              }
+              for (int e = 0; e < 8; ++e) v[e] *= vy_act_grad_fast<ACT>((float)g[e]);
             }
-            if (ep.residual) {
-              const bf16x8 r = *reinterpret_cast<const bf16x8*>(ep.residual + m * ep.ldr + n);
+          }
+          if (ep.residual) {
+            const bf16x8 r = (pf && !pf_is_gradpre) ? p8 : *reinterpret_cast<const bf16x8*>(ep.residual + m * ep.ldr + n);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-            }
-            if (ep.residual2) {
-              const bf16x8 r = *reinterpret_cast<const bf16x8*>(ep.residual2 + m * ep.ldr2 + n);
+            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+          }
+          if (ep.residual2) {
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(ep.residual2 + m * ep.ldr2 + n);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-            }
+            for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
           }
           bf16x8 o;
 #pragma unroll
@@ -383,17 +410,40 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
         } else {
           for (int e = 0; e < 8 && n + e < N; ++e) {
             float x = v[e];
-            if (final_pass) {
-              if constexpr (GRAD) {
-                if (ep.gradpre) x *= vy_act_grad_fast<ACT>((float)ep.gradpre[m * ep.ldg + n + e]);
-              }
-              if (ep.residual) x += (float)ep.residual[m * ep.ldr + n + e];
-              if (ep.residual2) x += (float)ep.residual2[m * ep.ldr2 + n + e];
+            if constexpr (GRAD) {
+              if (ep.gradpre) x *= vy_act_grad_fast<ACT>((float)ep.gradpre[m * ep.ldg + n + e]);
             }
+            if (ep.residual) x += (float)ep.residual[m * ep.ldr + n + e];
+            if (ep.residual2) x += (float)ep.residual2[m * ep.ldr2 + n + e];
             dst[m * ep.ldy + n + e] = (bf16)x;
           }
         }
+    };
+    constexpr bool PFK = PF_OK && PASSES == 1 && BM * BN == 256 * 192 && (RP * CPR) % NT == 0;   // kernels that prefetch (the 256 x 256 tile has no registers to spare: +5 % on FFN1 with them reserved)
+    constexpr int ITERS = PFK ? (RP * CPR) / NT : 1;
+    bf16x8 pre8[ITERS];
+    const bool pf_on = PFK && pf_ptr != nullptr && ep.vec_ok && m0 + BM <= M && n0 + BN <= N;   // workgroup-uniform
+    if constexpr (PFK) {
+      if (pf_on) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int c = tid + it * NT;
+          const int row = c / CPR, cc = c - row * CPR;
+          pre8[it] = *reinterpret_cast<const bf16x8*>(pf_ptr + (int64_t)(m0 + row) * pf_ld + n0 + cc * 8);
+        }
       }
+    }
+    auto flush_plain = [&](bf16* __restrict__ dst, bool final_pass, bool dual, int pass) {
+      (void)final_pass;
+      if constexpr (PFK) {
+        if (pf_on) {
+#pragma unroll
+          for (int it = 0; it < ITERS; ++it) do_chunk(dst, dual, pass, tid + it * NT, true, pre8[it]);
+          return;
+        }
+      }
+      const bf16x8 none{};
+      for (int c = tid; c < RP * CPR; c += NT) do_chunk(dst, dual, pass, c, false, none);
     };
     const bool dual = !GRAD && ep.pre != nullptr;   // (the GRAD path never sets ep.pre)
 #pragma unroll 1
@@ -424,8 +474,38 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
     // are the bf16-rounded projections, so the rotation reproduces the reference's op order
     // (Linear output in q.dtype, then q*cos + rotate_half(q)*sin with every op rounded:
     // VyomAI/layers/positional_embeddings.py:173-181) exactly.
+    // The rotary factors of the band's rows go through LDS: cos | sin of one position, rounded to bf16 once, are
+    // 128 bytes next to the staged tile, filled by 2 x 16-byte loads per thread and pass while the accumulators
+    // are being staged -- read per chunk from the fp32 tables they were 4 more loads per 16-byte store in a phase
+    // that is bound by the CU's vector-memory path (24 k cycles against 13 k for the same tile without RoPE).
+    constexpr bool TAB = epi_has_rope_tab(BM, BN, 1, PASSES);
+    char* rt = smem + RP * EROW;   // rotary table of the band: [RP][64] bf16
+    const bool use_tab = TAB && eq.rope && n0 < eq.nq + eq.nkv;
+    // row -> (batch, position) without 64-bit divisions: the tile's first row once, then 32-bit arithmetic
+    const unsigned Lu = (unsigned)eq.L;
+    const unsigned b0 = (unsigned)m0 / Lu, l0 = (unsigned)m0 - b0 * Lu;
+    const int64_t pdev = eq.pos_dev ? (int64_t)*eq.pos_dev : 0;
+    const int64_t pbase = eq.pos_dev ? pdev : eq.pos0;
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
+    constexpr int TIT = (RP * 8 + NT - 1) / NT;   // table chunks (8 bf16) per thread
+    f32x4 tv[TAB ? TIT : 1][2];
+    if constexpr (TAB) {
+      if (use_tab) {
+#pragma unroll
+        for (int it = 0; it < TIT; ++it) {
+          const int idx = tid + it * NT;
+          const int row = idx >> 3, ch = idx & 7;
+          if (RP * 8 % NT == 0 || idx < RP * 8) {
+            const unsigned t = l0 + (unsigned)(pass * RP + row);
+            const unsigned l = t - (t / Lu) * Lu;
+            const float* src = (ch < 4 ? eq.cos_tab : eq.sin_tab) + (pbase + l) * 32 + (ch & 3) * 8;
+            tv[it][0] = *reinterpret_cast<const f32x4*>(src);
+            tv[it][1] = *reinterpret_cast<const f32x4*>(src + 4);
+          }
+        }
+      }
+    }
     if (PASSES == 1 || pass == my_pass) {
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -442,32 +522,58 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
         }
       }
     }
+    if constexpr (TAB) {
+      if (use_tab) {
+#pragma unroll
+        for (int it = 0; it < TIT; ++it) {
+          const int idx = tid + it * NT;
+          if (RP * 8 % NT == 0 || idx < RP * 8) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (bf16)tv[it][0][e]; o[4 + e] = (bf16)tv[it][1][e]; }
+            *reinterpret_cast<bf16x8*>(rt + idx * 16) = o;
+          }
+        }
+      }
+    }
     __syncthreads();
     for (int c = tid; c < RP * CPR; c += NT) {
       const int row = c / CPR, cc = c - row * CPR;
       const int64_t m = m0 + pass * RP + row;
       const int n = n0 + cc * 8;
       if (m >= M || n >= N) continue;
-      const int64_t b = m / eq.L, l = m - b * eq.L;
+      const unsigned t = l0 + (unsigned)(pass * RP + row);
+      const unsigned tq = t / Lu;
+      const int64_t b = b0 + tq, l = t - tq * Lu;
       bf16x8 sv = *reinterpret_cast<const bf16x8*>(et + row * EROW + cc * 16);
       if (eq.rope && n < eq.nq + eq.nkv) {
         // dh == 64 and BN % 64 == 0: the partner chunk (d ^ 32) is in this tile row
         const bf16x8 pv = *reinterpret_cast<const bf16x8*>(et + row * EROW + (cc ^ 4) * 16);
         const int d = n & 31;
         const bool hi = (n & 32) != 0;
-        const int64_t pp = (eq.pos_dev ? (int64_t)*eq.pos_dev : eq.pos0) + l;
-        const float* cp = eq.cos_tab + pp * 32 + d;
-        const float* sp = eq.sin_tab + pp * 32 + d;
+        float cs[8], sn[8];
+        if (TAB && use_tab) {
+          const bf16x8 c8 = *reinterpret_cast<const bf16x8*>(rt + row * 128 + (d >> 3) * 16);
+          const bf16x8 s8 = *reinterpret_cast<const bf16x8*>(rt + row * 128 + 64 + (d >> 3) * 16);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { cs[e] = (float)c8[e]; sn[e] = (float)s8[e]; }
+        } else {
+          const float* cp = eq.cos_tab + (pbase + l) * 32 + d;
+          const float* sp = eq.sin_tab + (pbase + l) * 32 + d;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { cs[e] = vy_round_bf16(cp[e]); sn[e] = vy_round_bf16(sp[e]); }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float cs = vy_round_bf16(cp[e]), sn = vy_round_bf16(sp[e]);
           const float a = (float)sv[e], o = (float)pv[e];
-          const float t1 = vy_round_bf16(a * cs);
-          const float t2 = vy_round_bf16((hi ? o : -o) * sn);
+          const float t1 = vy_round_bf16(a * cs[e]);
+          const float t2 = vy_round_bf16((hi ? o : -o) * sn[e]);
           sv[e] = (bf16)(t1 + t2);
         }
       }
-      if (eq.vec8) {
+      if (eq.vec8 && eq.dh == 64) {
+        *reinterpret_cast<bf16x8*>(qkv_dest64(eq, b, l, n, l + pdev)) = sv;
+      } else if (eq.vec8) {
         *reinterpret_cast<bf16x8*>(qkv_dest(eq, b, l, n)) = sv;
       } else {
         for (int e = 0; e < 8 && n + e < N; ++e) *qkv_dest(eq, b, l, n + e) = sv[e];
@@ -497,7 +603,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
   constexpr int GX = (PX + NW - 1) / NW, GW = (PW + NW - 1) / NW;
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int EROW = BN * 2 + 16;                     // epilogue tile row (padded)
-  constexpr int LDS_BYTES = 2 * STAGE > BM * EROW ? 2 * STAGE : BM * EROW;
+  constexpr int LDS_BYTES = vy_cmax(2 * STAGE, epi_lds_bytes(BM, BN, EPI, 1));
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -662,7 +768,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
   constexpr int XT = BM * ROWB, WT = BN * ROWB;        // bytes of one X / W k-slice
   constexpr int WOFF = 3 * XT;
   constexpr int EROW = BN * 2 + 16;
-  constexpr int LDS_BYTES = 3 * XT + 2 * WT > BM * EROW ? 3 * XT + 2 * WT : BM * EROW;
+  constexpr int LDS_BYTES = vy_cmax(3 * XT + 2 * WT, epi_lds_bytes(BM, BN, EPI, 1));
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1032,7 +1138,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pipe_kernel(
     } else {
       // last tile of this workgroup: the staged epilogue (the ring is free: every wave is past the last barrier)
       EpiQkv<bf16> eq{};
-      gemm_epilogue<BM, BN, WGM, WGN, 0, ACT, false>(acc, smem, m0, n0, M, N, ep, eq);
+      gemm_epilogue<BM, BN, WGM, WGN, 0, ACT, false, 1, false>(acc, smem, m0, n0, M, N, ep, eq);
     }
   }
 }
@@ -1062,7 +1168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_pp_kernel(
   constexpr int EROW = BN * 2 + 16;
   constexpr int PASSES = 2;
   constexpr int LDS_BYTES = 3 * XT + 2 * WT;
-  static_assert((BM / PASSES) * EROW <= LDS_BYTES, "epilogue band must fit in the ring");
+  static_assert(epi_lds_bytes(BM, BN, EPI, PASSES) <= LDS_BYTES, "epilogue band (+ rotary table) must fit in the ring");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1221,7 +1327,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
   constexpr int GX = PX / NW, GW = (PW + NW - 1) / NW;  // per wave: 2 and 2 (the last may be absent)
   constexpr int STAGE = (BM + BN) * RROW;
   constexpr int EROW = BN * 2 + 16;
-  constexpr int LDS_BYTES = NS * STAGE > BM * EROW ? NS * STAGE : BM * EROW;
+  constexpr int LDS_BYTES = vy_cmax(NS * STAGE, epi_lds_bytes(BM, BN, EPI, 1));
   static_assert(PX % NW == 0, "X pieces must divide over the waves");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
