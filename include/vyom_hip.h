@@ -368,7 +368,11 @@ typedef struct vy_gemma_plan {
   const vy_gemma_layer* layers;
   const void* norm_w; const void* head_w;  /* final RMSNorm, [vocab, d] projection */
   void* ws; int64_t ws_bytes;              /* >= vy_gemma_ws_bytes(...) */
+  int32_t flags;                           /* VY_GEMMA_PRESCALED: every layer's wqkv / wgu is already multiplied by
+                                              (1 + ln_in) / (1 + ln_post) along K (bf16, B <= 4): the step skips the
+                                              RMSNorm launches and scales each product by rsqrt(mean x^2 + eps) */
 } vy_gemma_plan;
+#define VY_GEMMA_PRESCALED 1
 int64_t vy_gemma_ws_bytes(int32_t B, int32_t d, int32_t h, int32_t dh, int32_t ffn, int32_t dtype);
 /* x: (B, d) embeddings of the current token (already scaled by sqrt(d)); keys 0..pos are attended;
  * logits: (B, ldv). */

@@ -203,3 +203,56 @@ def test_model_and_cached_greedy_loop_fp32_vs_notebook(golden):
     before = m.norm.weight.detach().clone()
     m.load_reference_state_dict(ref_sd)
     assert torch.allclose(m.norm.weight, before + 1.0)
+
+
+def test_single_sequence_step_lean_kernels_vs_general_and_fp32(monkeypatch):
+    """B = 1 bf16 decode at the true Gemma-2B widths (d 2048, 8 x 256 query heads on one KV head, MLP 16384): the
+    straight-line matrix-vector kernels with the RMSNorms folded into pre-scaled weights and the rotary embedding
+    fused into the QKV product (vy_decode.hip) against the general chain (RMSNorm / QKV / RoPE launches), and both
+    against the fp32 step on the same weights and cache contents: same error level."""
+    import ctypes as C
+    from vyomai_amd import _lib
+    from vyomai_amd.decode_plan import GemmaDecodePlan
+    from vyomai_amd.models import paligemma as P
+    lib = _lib.load()
+    lib.vy_debug_set_gemma_lean.argtypes = [C.c_int]
+    vis = P.SiglipVisionConfig(**dict(cases.SIGLIP, num_hidden_layers=1))
+    txt = types.SimpleNamespace(**dict(cases.GEMMA, num_hidden_layers=2, vocab_size=4096))
+
+    def model(dt):
+        m = P.PaliGemmaForConditionalGeneration(P.PaliGemmaShape(vis, txt, txt.hidden_size))
+        for n, p in m.named_parameters():
+            with torch.no_grad():
+                p.copy_(T(recipe.param_value("pgl." + n, tuple(p.shape))))
+        return m.to(DEV).to(dt).eval()
+
+    def caches(dt):
+        g = torch.Generator().manual_seed(3)
+        return [(torch.randn(1, 1, 64, 256, generator=g).to(dt).to(DEV), torch.randn(1, 1, 64, 256, generator=g).to(dt).to(DEV))
+                for _ in range(2)]
+
+    x = (torch.randn(1, txt.hidden_size, generator=torch.Generator().manual_seed(4)) * 0.3)
+    pos = 40
+    m16, m32 = model(torch.bfloat16), model(torch.float32)
+    res = {}
+    try:
+        for name, lean, prescale in (("lean", 1, "1"), ("lean_noscale", 1, "0"), ("general", 0, "0")):
+            monkeypatch.setenv("VY_GEMMA_PRESCALE", prescale)
+            lib.vy_debug_set_gemma_lean(lean)
+            cs = caches(torch.bfloat16)
+            plan = GemmaDecodePlan(m16, cs, 1)
+            res[name] = (plan.step(x.to(torch.bfloat16).to(DEV), pos).float().clone(),
+                         [c[0][:, :, pos].float().clone() for c in cs])
+            torch.cuda.synchronize()
+    finally:
+        lib.vy_debug_set_gemma_lean(1)
+    cs32 = caches(torch.float32)
+    ref = GemmaDecodePlan(m32, cs32, 1).step(x.to(DEV), pos).float()
+    e = {k: (v[0] - ref).abs().mean().item() for k, v in res.items()}
+    scale = ref.abs().mean().item()
+    assert e["general"] < 0.05 * scale + 1e-3, (e, scale)           # the bf16 error level of the general chain
+    assert e["lean"] <= 1.3 * e["general"] + 2e-3 * scale, (e, scale)
+    assert e["lean_noscale"] <= 1.3 * e["general"] + 2e-3 * scale, (e, scale)
+    for name in ("lean", "lean_noscale"):   # rotated K rows written into the cache
+        for a, b in zip(res[name][1], res["general"][1]):
+            assert (a - b).abs().max().item() <= 0.05 * max(1.0, b.abs().max().item()), name

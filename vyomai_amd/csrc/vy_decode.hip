@@ -418,6 +418,133 @@ int dec_part64_go(DecGemmArgs a, int K, hipStream_t st) {
   return chunks;
 }
 
+// ------------------------------------------------------------------------------------------
+// Single-sequence matrix-vector products (Gemma-style decode, B = 1: BASELINE configs[4]).  One wave per output
+// column, the row of the weight matrix in 16-byte pieces (1 KiB contiguous per wave instruction).  The general
+// gemv_bf16_kernel (vy_gemm.hip) serves up to 4 rows with run-time row guards, and its ISA shows what that costs:
+// the activation chunk of every k-piece is requested and waited for (vmcnt(0)) in the middle of the dot products,
+// one dependent round trip per piece.  Here the row count is 1 and the piece count a template constant: straight-
+// line code, the loads of batch b + 1 issued before the dot products of batch b, waits counted by the compiler.
+//   NORM: the weights carry the preceding RMSNorm's (1 + w) along K; the wave accumulates sum x^2 from the chunks
+//         it holds anyway and scales its result by rsqrt(mean x^2 + eps)              (no RMSNorm launch)
+//   GV_QKV: rotary embedding fused: the four waves of a workgroup take the columns {d, d+1, d+dh/2, d+1+dh/2} of one
+//         head and swap partners through LDS (rope2_kernel's arithmetic, vy_misc.hip)   (no RoPE launch)
+// ------------------------------------------------------------------------------------------
+enum { GV_PLAIN = 0, GV_GATED = 1, GV_QKV = 2 };
+struct DecGemvArgs {
+  const bf16* x; const bf16* w; const bf16* bias; const bf16* residual; bf16* y;
+  int N, K, ldw;
+  float eps;
+  // GV_QKV
+  bf16* q; bf16* k; bf16* v; long long c_sh;   // q [nq]; k / v: cache row of this position, head stride c_sh
+  const float* cos_tab; const float* sin_tab; int pos, nq, nkv, dh;
+};
+
+template <int EPI, int CH, int NB, bool NORM>
+__global__ __launch_bounds__(256) void dec_gemv1_kernel(const DecGemvArgs p) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  __shared__ float rope_x[4];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int n = (int)blockIdx.x * 4 + wv;
+  const bool rope_on = EPI == GV_QKV && p.cos_tab != nullptr;
+  if (rope_on) {
+    const int per_head = p.dh >> 2;
+    const int hd = (int)blockIdx.x / per_head, pi = (int)blockIdx.x - hd * per_head;
+    n = hd * p.dh + 2 * pi + (wv & 1) + (p.dh >> 1) * (wv >> 1);
+  }
+  const bf16* wp = p.w + (long long)n * p.ldw + lane * 8;
+  const bf16* wp2 = p.w + (long long)(p.N + n) * p.ldw + lane * 8;   // GV_GATED: the "up" row
+  const bf16* xp = p.x + lane * 8;
+  float acc = 0.f, acc2 = 0.f, sq = 0.f;
+  bf16x8 wa[2][CH], wb[2][CH], xa[2][CH];
+  auto issue = [&](int b, int buf) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int off = (b * CH + u) * 512;
+      wa[buf][u] = *reinterpret_cast<const bf16x8*>(wp + off);
+      if constexpr (EPI == GV_GATED) wb[buf][u] = *reinterpret_cast<const bf16x8*>(wp2 + off);
+      xa[buf][u] = *reinterpret_cast<const bf16x8*>(xp + off);
+    }
+  };
+  issue(0, 0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b + 1 < NB) issue(b + 1, (b + 1) & 1);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      union { bf16x8 v; bf16x2_t h[4]; } a, a2, x;
+      a.v = wa[b & 1][u];
+      x.v = xa[b & 1][u];
+      if constexpr (EPI == GV_GATED) a2.v = wb[b & 1][u];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc = __builtin_amdgcn_fdot2_f32_bf16(a.h[e], x.h[e], acc, false);
+        if constexpr (EPI == GV_GATED) acc2 = __builtin_amdgcn_fdot2_f32_bf16(a2.h[e], x.h[e], acc2, false);
+        if constexpr (NORM) sq = __builtin_amdgcn_fdot2_f32_bf16(x.h[e], x.h[e], sq, false);
+      }
+    }
+  }
+  acc = dec_wave_sum(acc);
+  if constexpr (EPI == GV_GATED) acc2 = dec_wave_sum(acc2);
+  if constexpr (NORM) {
+    const float ms = dec_wave_sum(sq) / (float)p.K + p.eps;
+    const float r = rsqrtf(ms);
+    const float rr = r * (1.5f - 0.5f * ms * r * r);
+    acc *= rr;
+    acc2 *= rr;
+  }
+  if constexpr (EPI == GV_PLAIN) {
+    if (lane == 0) {
+      float x = acc;
+      if (p.bias) x += (float)p.bias[n];
+      if (p.residual) x += (float)p.residual[n];
+      p.y[n] = (bf16)x;
+    }
+  } else if constexpr (EPI == GV_GATED) {
+    if (lane == 0) {
+      const float gte = vy_round_bf16(acc), up = vy_round_bf16(acc2);
+      p.y[n] = (bf16)(vy_gelu_tanh(gte) * up);
+    }
+  } else {
+    float x = acc;
+    if (p.bias) x += (float)p.bias[n];
+    x = vy_round_bf16(x);   // the projection as the unfused path stores it
+    float o = x;
+    if (rope_on) {
+      if (lane == 0) rope_x[wv] = x;
+      __syncthreads();
+      if (n < p.nq + p.nkv) {
+        const int half = p.dh >> 1;
+        const int d = (n & (p.dh - 1)) & (half - 1);
+        const float other = rope_x[wv ^ 2];
+        const long long pp = (long long)p.pos * half + d;
+        const float c = vy_round_bf16(p.cos_tab[pp]), sn = vy_round_bf16(p.sin_tab[pp]);
+        o = (wv < 2) ? vy_round_bf16(x * c) + vy_round_bf16(-other * sn) : vy_round_bf16(x * c) + vy_round_bf16(other * sn);
+      }
+    }
+    if (lane == 0) {
+      const int dlow = n & (p.dh - 1);
+      bf16* dst;
+      if (n < p.nq) dst = p.q + n;
+      else if (n < p.nq + p.nkv) dst = p.k + (long long)((n - p.nq) / p.dh) * p.c_sh + dlow;
+      else dst = p.v + (long long)((n - p.nq - p.nkv) / p.dh) * p.c_sh + dlow;
+      *dst = (bf16)o;
+    }
+  }
+}
+
+template <int EPI, bool NORM>
+int dec_gemv1_go(const DecGemvArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)(a.N / 4)), block(256);
+  if (a.K == 2048) hipLaunchKernelGGL((dec_gemv1_kernel<EPI, 4, 1, NORM>), grid, block, 0, st, a);
+  else if (a.K == 4096) hipLaunchKernelGGL((dec_gemv1_kernel<EPI, 8, 1, NORM>), grid, block, 0, st, a);
+  else if (a.K == 8192) hipLaunchKernelGGL((dec_gemv1_kernel<EPI, 8, 2, NORM>), grid, block, 0, st, a);
+  else if (a.K == 16384) hipLaunchKernelGGL((dec_gemv1_kernel<EPI, 8, 4, NORM>), grid, block, 0, st, a);
+  else return 1;
+  return 0;
+}
+
 }  // namespace
 
 // K ranges a workgroup of dec_gemm16_kernel can take: 4 waves x {4, 6, 8} k-steps of 32
@@ -512,4 +639,41 @@ int vy_dec_linear_res_ln(const void* x, int ldx, const void* w, const void* bias
 extern "C" int vy_debug_set_decode_stamps(void* buf, int launches, int max_wg) {
   g_dbg.buf = (unsigned long long*)buf; g_dbg.slot = 0; g_dbg.max_wg = max_wg; g_dbg_launches = launches;
   return 0;
+}
+
+// ---- single-sequence (B = 1) products of the Gemma-style decode step; return VY_ERR_UNSUPPORTED (without an error
+// message being fatal: the driver falls back to the general kernels) for shapes the straight-line kernels do not cover
+static bool gemv1_ok(const void* x, const void* w, int N, int K) {
+  return N % 4 == 0 && (K == 2048 || K == 4096 || K == 8192 || K == 16384) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0);
+}
+int vy_dec_gemv1(const void* x, const void* w, const void* bias, const void* residual, void* y, int N, int K, int prescaled,
+                 float eps, hipStream_t st) {
+  if (!gemv1_ok(x, w, N, K)) return VY_ERR_UNSUPPORTED;
+  DecGemvArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const bf16*)bias; a.residual = (const bf16*)residual; a.y = (bf16*)y;
+  a.N = N; a.K = K; a.ldw = K; a.eps = eps;
+  if (prescaled ? dec_gemv1_go<GV_PLAIN, true>(a, st) : dec_gemv1_go<GV_PLAIN, false>(a, st)) return VY_ERR_UNSUPPORTED;
+  VY_CHECK_LAUNCH("vy_dec_gemv1");
+  return VY_OK;
+}
+int vy_dec_gemv1_gated(const void* x, const void* wgu, void* y, int I, int K, int prescaled, float eps, hipStream_t st) {
+  if (!gemv1_ok(x, wgu, I, K)) return VY_ERR_UNSUPPORTED;
+  DecGemvArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)wgu; a.y = (bf16*)y; a.N = I; a.K = K; a.ldw = K; a.eps = eps;
+  if (prescaled ? dec_gemv1_go<GV_GATED, true>(a, st) : dec_gemv1_go<GV_GATED, false>(a, st)) return VY_ERR_UNSUPPORTED;
+  VY_CHECK_LAUNCH("vy_dec_gemv1_gated");
+  return VY_OK;
+}
+int vy_dec_gemv1_qkv(const void* x, const void* w, const void* bias, void* q, void* k, void* v, int64_t c_sh, int h, int hk,
+                     int dh, const float* cos_tab, const float* sin_tab, int64_t pos, int K, int prescaled, float eps,
+                     hipStream_t st) {
+  const int N = (h + 2 * hk) * dh;
+  if (!gemv1_ok(x, w, N, K) || dh % 4 || (dh & (dh - 1))) return VY_ERR_UNSUPPORTED;
+  DecGemvArgs a{};
+  a.x = (const bf16*)x; a.w = (const bf16*)w; a.bias = (const bf16*)bias; a.N = N; a.K = K; a.ldw = K; a.eps = eps;
+  a.q = (bf16*)q; a.k = (bf16*)k; a.v = (bf16*)v; a.c_sh = c_sh; a.cos_tab = cos_tab; a.sin_tab = sin_tab; a.pos = (int)pos;
+  a.nq = h * dh; a.nkv = hk * dh; a.dh = dh;
+  if (prescaled ? dec_gemv1_go<GV_QKV, true>(a, st) : dec_gemv1_go<GV_QKV, false>(a, st)) return VY_ERR_UNSUPPORTED;
+  VY_CHECK_LAUNCH("vy_dec_gemv1_qkv");
+  return VY_OK;
 }

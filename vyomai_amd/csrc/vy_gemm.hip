@@ -2040,22 +2040,36 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(
 // launch per projection from a single-sequence decode step.  GATED: W is the packed [gate; up] matrix
 // ([2 I, K]); the wave of output column n reads rows n and I + n and stores act(bf16 gate) * bf16 up
 // (GemmaMLP, cell 11; the arithmetic of gated_act_kernel on the two rounded projections).
-template <int EPI, int ACT, int MR, bool NORM = false, bool GATED = false>
+// NORM: 0 none; 1 RMSNorm of the input folded in (row statistics + per-element normalisation in every wave); 2 the
+// weights come pre-multiplied by the norm's (1 + w) along K, so the wave only accumulates sum x^2 beside the product
+// and scales its result by rsqrt(mean x^2 + eps) -- no RMSNorm launch, no per-element work.
+// EPI == 1 with eq.rope: rotary embedding fused (single-token rows): a workgroup's four waves take the columns
+// {d, d+1, d+dh/2, d+1+dh/2} of one head and swap partners through LDS (rope2_kernel's arithmetic).
+template <int EPI, int ACT, int MR, int NORM = 0, bool GATED = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx,
                                                         const bf16* __restrict__ W, int64_t ldw, int M, int N, int K,
                                                         EpiPlain<bf16> ep, EpiQkv<bf16> eq,
                                                         const bf16* __restrict__ norm_w, float norm_eps) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
+  int n = blockIdx.x * 4 + wv;
+  const bool rope_on = EPI == 1 && eq.rope;   // (the launcher guarantees N % 4 == 0 and dh % 4 == 0 then)
+  if (rope_on) {
+    const int per_head = eq.dh >> 2;
+    const int hd = (int)blockIdx.x / per_head, pi = (int)blockIdx.x - hd * per_head;
+    n = hd * eq.dh + 2 * pi + (wv & 1) + (eq.dh >> 1) * (wv >> 1);
+  }
   if (n >= N) return;   // wave-uniform
   const bf16* w = W + (int64_t)n * ldw;
   const bf16* w2 = GATED ? W + (int64_t)(N + n) * ldw : nullptr;
   float acc[MR], acc2[MR];
 #pragma unroll
   for (int m = 0; m < MR; ++m) { acc[m] = 0.f; acc2[m] = 0.f; }
-  float rstd[MR];
-  if constexpr (NORM) {
+  float rstd[MR], sq[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) { rstd[m] = 1.f; sq[m] = 0.f; }
+  if constexpr (NORM == 1) {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       float q = 0.f;
@@ -2088,14 +2102,18 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
         a.v = wv[u];
         if constexpr (GATED) a2.v = wv2[u];
         bf16x8 g8;
-        if constexpr (NORM) g8 = *reinterpret_cast<const bf16x8*>(norm_w + kk);
+        if constexpr (NORM == 1) g8 = *reinterpret_cast<const bf16x8*>(norm_w + kk);
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
           if (m < M) {
             b.v = *reinterpret_cast<const bf16x8*>(X + (int64_t)m * ldx + kk);
-            if constexpr (NORM) {
+            if constexpr (NORM == 1) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) b.v[e] = (bf16)((float)b.v[e] * rstd[m] * (1.0f + (float)g8[e]));
+            }
+            if constexpr (NORM == 2) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sq[m] = __builtin_amdgcn_fdot2_f32_bf16(b.h[e], b.h[e], sq[m], false);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -2111,6 +2129,42 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
   for (int m = 0; m < MR; ++m) {
     acc[m] = vy_wave_sum(acc[m]);
     if constexpr (GATED) acc2[m] = vy_wave_sum(acc2[m]);
+    if constexpr (NORM == 2) {
+      const float ms = vy_wave_sum(sq[m]) / (float)K + norm_eps;
+      const float r = rsqrtf(ms);
+      const float rr = r * (1.5f - 0.5f * ms * r * r);
+      acc[m] *= rr;
+      if constexpr (GATED) acc2[m] *= rr;
+    }
+  }
+  __shared__ float rope_x[4][MR];
+  if constexpr (EPI == 1) {
+    if (rope_on) {   // workgroup-uniform: every wave of the workgroup is here
+      if (lane < MR) {
+        float x = 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) x = lane == m ? acc[m] : x;
+        if (eq.bias) x += (float)eq.bias[n];
+        rope_x[wv][lane] = vy_round_bf16(x);   // the projection as the unfused path stores it
+      }
+      __syncthreads();
+      if (lane < M && lane < MR) {
+        const int64_t m = lane;
+        const int half = eq.dh >> 1;
+        const int d = (n % eq.dh) & (half - 1);   // index of the rotary pair (dh is a power of two here)
+        float o = rope_x[wv][lane];
+        if (n < eq.nq + eq.nkv) {
+          const float mine = o, other = rope_x[wv ^ 2][lane];
+          const int64_t pp = (eq.pos_dev ? (int64_t)*eq.pos_dev : eq.pos0) * half + d;
+          const float c = vy_round_bf16(eq.cos_tab[pp]), sn = vy_round_bf16(eq.sin_tab[pp]);
+          // rope2_kernel: low half a*c + (-b*s), high half b*c + a*s, every product rounded to bf16
+          o = (wv < 2) ? vy_round_bf16(mine * c) + vy_round_bf16(-other * sn)
+                       : vy_round_bf16(mine * c) + vy_round_bf16(other * sn);
+        }
+        *qkv_dest(eq, m, 0, n) = (bf16)o;
+      }
+      return;
+    }
   }
   if (lane < M && lane < MR) {
     float x = 0.f, x2 = 0.f;
@@ -2504,6 +2558,9 @@ int vy_linear_res_ln_skinny(const void* x, int64_t ldx, const void* w, int64_t l
 
 // Single-sequence (M <= 4) bf16 projections with the RMSNorm of their input fused in (internal: the Gemma decode
 // driver).  norm_w NULL = no norm.  vy_gemv_gated: w = packed [gate; up] ([2 I, K]) -> y[M, I] = act(gate) * up.
+// norm_w of the launchers below: NULL = no norm, VY_NORM_PRESCALED = the weights carry the norm's (1 + w) (mode 2),
+// anything else = the RMSNorm weight vector (mode 1)
+#define VY_NORM_PRESCALED ((const void*)(intptr_t)-1)
 static bool gemv_ok(const void* x, int64_t ldx, const void* w, int64_t ldw, int64_t M, int64_t K) {
   return M >= 1 && M <= 4 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0);
 }
@@ -2514,19 +2571,24 @@ int vy_gemv_norm(const void* x, int64_t ldx, const void* w, int64_t ldw, const v
   ep.bias = (const bf16*)bias; ep.residual = (const bf16*)residual; ep.ldr = ldr; ep.y = (bf16*)y; ep.ldy = ldy;
   EpiQkv<bf16> eq{};
   const dim3 grid((unsigned)vy_cdiv(N, 4)), block(256);
-  if (norm_w)
-    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_NONE, 4, true, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+  if (norm_w == VY_NORM_PRESCALED)
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_NONE, 4, 2, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)M, (int)N, (int)K, ep, eq, (const bf16*)nullptr, eps);
+  else if (norm_w)
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_NONE, 4, 1, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
                        (const bf16*)w, ldw, (int)M, (int)N, (int)K, ep, eq, (const bf16*)norm_w, eps);
   else
-    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_NONE, 4, false, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_NONE, 4, 0, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
                        (const bf16*)w, ldw, (int)M, (int)N, (int)K, ep, eq, (const bf16*)nullptr, 0.f);
   VY_CHECK_LAUNCH("vy_gemv_norm");
   return VY_OK;
 }
 int vy_gemv_qkv_norm(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, const void* norm_w, float eps,
                      void* q, int64_t q_sb, int64_t q_sh, void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl, void* v,
-                     int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t K, int h, int hk, int dh, void* stream) {
-  // packed [q | k | v] projection of single-token rows (L = 1), no rotary (applied by vy_rope_qk afterwards)
+                     int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t K, int h, int hk, int dh,
+                     const float* cos_tab, const float* sin_tab, int64_t pos, void* stream) {
+  // packed [q | k | v] projection of single-token rows (L = 1); cos_tab != NULL: rotary embedding at position `pos`
+  // fused (head widths that are a power of two and a multiple of 4), else applied by vy_rope_qk afterwards
   if (!gemv_ok(x, ldx, w, ldw, B, K)) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_gemv_qkv_norm: needs B <= 4 and 16-byte aligned rows");
   EpiPlain<bf16> ep{};
   EpiQkv<bf16> eq{};
@@ -2534,13 +2596,20 @@ int vy_gemv_qkv_norm(const void* x, int64_t ldx, const void* w, int64_t ldw, con
   eq.k = (bf16*)k; eq.k_sb = k_sb; eq.k_sh = k_sh; eq.k_sl = k_sl;
   eq.v = (bf16*)v; eq.v_sb = v_sb; eq.v_sh = v_sh; eq.v_sl = v_sl;
   eq.L = 1; eq.nq = h * dh; eq.nkv = hk * dh; eq.dh = dh; eq.rope = 0; eq.vec8 = 0; eq.pos_dev = nullptr;
+  if (cos_tab) {
+    if (dh % 4 || (dh & (dh - 1)) || !sin_tab) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_gemv_qkv_norm: fused rotary needs a power-of-two head width");
+    eq.rope = 1; eq.cos_tab = cos_tab; eq.sin_tab = sin_tab; eq.pos0 = pos;
+  }
   const int64_t N = (int64_t)(h + 2 * hk) * dh;
   const dim3 grid((unsigned)vy_cdiv(N, 4)), block(256);
-  if (norm_w)
-    hipLaunchKernelGGL((gemv_bf16_kernel<1, VY_ACT_NONE, 4, true, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+  if (norm_w == VY_NORM_PRESCALED)
+    hipLaunchKernelGGL((gemv_bf16_kernel<1, VY_ACT_NONE, 4, 2, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)B, (int)N, (int)K, ep, eq, (const bf16*)nullptr, eps);
+  else if (norm_w)
+    hipLaunchKernelGGL((gemv_bf16_kernel<1, VY_ACT_NONE, 4, 1, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
                        (const bf16*)w, ldw, (int)B, (int)N, (int)K, ep, eq, (const bf16*)norm_w, eps);
   else
-    hipLaunchKernelGGL((gemv_bf16_kernel<1, VY_ACT_NONE, 4, false, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+    hipLaunchKernelGGL((gemv_bf16_kernel<1, VY_ACT_NONE, 4, 0, false>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
                        (const bf16*)w, ldw, (int)B, (int)N, (int)K, ep, eq, (const bf16*)nullptr, 0.f);
   VY_CHECK_LAUNCH("vy_gemv_qkv_norm");
   return VY_OK;
@@ -2553,11 +2622,14 @@ int vy_gemv_gated(const void* x, int64_t ldx, const void* w, int64_t ldw, const 
   ep.y = (bf16*)y; ep.ldy = ldy;
   EpiQkv<bf16> eq{};
   const dim3 grid((unsigned)vy_cdiv(I, 4)), block(256);
-  if (norm_w)
-    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_GELU_TANH, 4, true, true>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+  if (norm_w == VY_NORM_PRESCALED)
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_GELU_TANH, 4, 2, true>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                       (const bf16*)w, ldw, (int)M, (int)I, (int)K, ep, eq, (const bf16*)nullptr, eps);
+  else if (norm_w)
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_GELU_TANH, 4, 1, true>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
                        (const bf16*)w, ldw, (int)M, (int)I, (int)K, ep, eq, (const bf16*)norm_w, eps);
   else
-    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_GELU_TANH, 4, false, true>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
+    hipLaunchKernelGGL((gemv_bf16_kernel<0, VY_ACT_GELU_TANH, 4, 0, true>), grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx,
                        (const bf16*)w, ldw, (int)M, (int)I, (int)K, ep, eq, (const bf16*)nullptr, 0.f);
   VY_CHECK_LAUNCH("vy_gemv_gated");
   return VY_OK;

@@ -17,7 +17,9 @@ int vy_gemv_norm(const void* x, int64_t ldx, const void* w, int64_t ldw, const v
                  const void* residual, int64_t ldr, void* y, int64_t ldy, int64_t M, int64_t N, int64_t K, void* stream);
 int vy_gemv_qkv_norm(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, const void* norm_w, float eps,
                      void* q, int64_t q_sb, int64_t q_sh, void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl, void* v,
-                     int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t K, int h, int hk, int dh, void* stream);
+                     int64_t v_sb, int64_t v_sh, int64_t v_sl, int64_t B, int64_t K, int h, int hk, int dh,
+                     const float* cos_tab, const float* sin_tab, int64_t pos, void* stream);
+#define VY_NORM_PRESCALED ((const void*)(intptr_t)-1)
 int vy_gemv_gated(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* norm_w, float eps, void* y, int64_t ldy,
                   int64_t M, int64_t I, int64_t K, int act, void* stream);
 int vy_rope_qk(void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl, int hq, void* k, int64_t k_sb, int64_t k_sh,
@@ -40,8 +42,17 @@ int vy_dec_linear_res_ln(const void* x, int ldx, const void* w, const void* bias
                          int act, hipStream_t st);
 
 static int g_decode_lean = -1;
+static int g_gemma_lean = -1;
+extern "C" int vy_debug_set_gemma_lean(int v) { g_gemma_lean = v; return 0; }   // test aid: 0 = general kernels for B = 1 too
 // measurement / test aid, not part of include/vyom_hip.h: 0 = general launchers, 1 = the decode-only kernels
 extern "C" int vy_debug_set_decode_lean(int v) { g_decode_lean = v; return 0; }
+
+int vy_dec_gemv1(const void* x, const void* w, const void* bias, const void* residual, void* y, int N, int K, int prescaled,
+                 float eps, hipStream_t st);
+int vy_dec_gemv1_gated(const void* x, const void* wgu, void* y, int I, int K, int prescaled, float eps, hipStream_t st);
+int vy_dec_gemv1_qkv(const void* x, const void* w, const void* bias, void* q, void* k, void* v, int64_t c_sh, int h, int hk,
+                     int dh, const float* cos_tab, const float* sin_tab, int64_t pos, int K, int prescaled, float eps,
+                     hipStream_t st);
 
 namespace {
 inline int64_t esize(int dtype) { return dtype == VY_BF16 ? 2 : 4; }
@@ -202,31 +213,79 @@ extern "C" int vy_gemma_decoder_step(const vy_gemma_plan* p, const void* x, int6
   // (folding the RMSNorm into the products as well -- VY_GEMMA_FUSED=2 -- measured SLOWER, 2.05 vs 1.76 ms per token:
   // every one of the N waves of a product redoes the row statistics and the normalisation of its input)
   const bool fold_norm = fused_env >= 2;
+  const bool prescaled = fused && (p->flags & VY_GEMMA_PRESCALED);
+  static const int rope_env = [] { const char* e = getenv("VY_GEMMA_ROPE_FUSED"); return e ? atoi(e) : 1; }();
+  const bool rope_fused = fused && rope_env && p->cos_tab && dh % 4 == 0 && (dh & (dh - 1)) == 0;
+  if (g_gemma_lean < 0) { const char* e = getenv("VY_GEMMA_LEAN"); g_gemma_lean = e ? atoi(e) : 1; }
+  const bool lean1 = g_gemma_lean && B == 1 && !fold_norm;
   for (int l = 0; l < p->num_layers; ++l) {
     const vy_gemma_layer& L = p->layers[l];
     void* kdst = (char*)L.kcache + pos * L.c_sl * e;
     void* vdst = (char*)L.vcache + pos * L.c_sl * e;
     void* nxt = hb[l & 1];
-    if (fused) {
+    if (fused && lean1) {
+      // one sequence: the straight-line matrix-vector kernels of vy_decode.hip (norms folded when the plan's weights
+      // are pre-scaled, rotary pairs swapped inside the QKV product); any unsupported shape -> the general chain below
+      hipStream_t hs = (hipStream_t)stream;
       const void* qin = cur;
-      if (!fold_norm) {
+      if (!prescaled) {
         if ((rc = vy_rmsnorm_fwd(cur, d, L.ln_in, n, d, B, d, p->eps, 1.0f, p->dtype, stream))) return rc;
         qin = n;
       }
-      if ((rc = vy_gemv_qkv_norm(qin, d, L.wqkv, d, L.bqkv, fold_norm ? L.ln_in : nullptr, p->eps, q, (int64_t)h * dh, dh, kdst, L.c_sb, L.c_sh,
-                                 L.c_sl, vdst, L.c_sb, L.c_sh, L.c_sl, B, d, h, hk, dh, stream))) return rc;
-      if (p->cos_tab && (rc = vy_rope_qk(q, (int64_t)h * dh, dh, dh, h, kdst, L.c_sb, L.c_sh, L.c_sl, hk, p->cos_tab, p->sin_tab,
-                                         pos, B, 1, dh, p->dtype, (hipStream_t)stream))) return rc;
+      rc = vy_dec_gemv1_qkv(qin, L.wqkv, L.bqkv, q, kdst, vdst, L.c_sh, h, hk, dh, rope_fused ? p->cos_tab : nullptr, p->sin_tab,
+                            pos, d, prescaled, p->eps, hs);
+      if (rc == VY_OK) {
+        if (p->cos_tab && !rope_fused &&
+            (rc = vy_rope_qk(q, (int64_t)h * dh, dh, dh, h, kdst, L.c_sb, L.c_sh, L.c_sl, hk, p->cos_tab, p->sin_tab,
+                             pos, B, 1, dh, p->dtype, hs))) return rc;
+        if ((rc = vy_attn_decode_ex(q, (int64_t)h * dh, dh, L.kcache, L.c_sb, L.c_sh, L.c_sl, L.vcache, L.c_sb, L.c_sh, L.c_sl,
+                                    ao, (int64_t)h * dh, B, h, hk, pos + 1, nullptr, dh, scale, p->dtype, stream))) return rc;
+        if ((rc = vy_dec_gemv1(ao, L.wo, L.bo, cur, x1, d, h * dh, 0, 0.f, hs))) {
+          if ((rc = vy_gemv_norm(ao, (int64_t)h * dh, L.wo, (int64_t)h * dh, L.bo, nullptr, 0.f, cur, d, x1, d, B, d,
+                                 (int64_t)h * dh, stream))) return rc;
+        }
+        const void* gin = x1;
+        if (!prescaled) {
+          if ((rc = vy_rmsnorm_fwd(x1, d, L.ln_post, n, d, B, d, p->eps, 1.0f, p->dtype, stream))) return rc;
+          gin = n;
+        }
+        if ((rc = vy_dec_gemv1_gated(gin, L.wgu, act, ffn, d, prescaled, p->eps, hs))) {
+          if ((rc = vy_gemv_gated(gin, d, L.wgu, d, prescaled ? VY_NORM_PRESCALED : nullptr, p->eps, act, ffn, B, ffn, d,
+                                  VY_ACT_GELU_TANH, stream))) return rc;
+        }
+        if ((rc = vy_dec_gemv1(act, L.wdown, nullptr, x1, nxt, d, ffn, 0, 0.f, hs))) {
+          if ((rc = vy_gemv_norm(act, ffn, L.wdown, ffn, nullptr, nullptr, 0.f, x1, d, nxt, d, B, d, ffn, stream))) return rc;
+        }
+        cur = nxt;
+        continue;
+      }
+    }
+    if (fused) {
+      // prescaled: the weights carry the norms' (1 + w), the products scale themselves by the row's rsqrt(mean x^2):
+      // no RMSNorm launch; rope_fused: rotary pairs swapped inside the QKV product's workgroups: no RoPE launch
+      const void* qin = cur;
+      const void* qnorm = prescaled ? VY_NORM_PRESCALED : (fold_norm ? L.ln_in : nullptr);
+      if (!fold_norm && !prescaled) {
+        if ((rc = vy_rmsnorm_fwd(cur, d, L.ln_in, n, d, B, d, p->eps, 1.0f, p->dtype, stream))) return rc;
+        qin = n;
+      }
+      if ((rc = vy_gemv_qkv_norm(qin, d, L.wqkv, d, L.bqkv, qnorm, p->eps, q, (int64_t)h * dh, dh, kdst, L.c_sb, L.c_sh,
+                                 L.c_sl, vdst, L.c_sb, L.c_sh, L.c_sl, B, d, h, hk, dh, rope_fused ? p->cos_tab : nullptr,
+                                 p->sin_tab, pos, stream))) return rc;
+      if (p->cos_tab && !rope_fused &&
+          (rc = vy_rope_qk(q, (int64_t)h * dh, dh, dh, h, kdst, L.c_sb, L.c_sh, L.c_sl, hk, p->cos_tab, p->sin_tab,
+                           pos, B, 1, dh, p->dtype, (hipStream_t)stream))) return rc;
       if ((rc = vy_attn_decode_ex(q, (int64_t)h * dh, dh, L.kcache, L.c_sb, L.c_sh, L.c_sl, L.vcache, L.c_sb, L.c_sh, L.c_sl,
                                   ao, (int64_t)h * dh, B, h, hk, pos + 1, nullptr, dh, scale, p->dtype, stream))) return rc;
       if ((rc = vy_gemv_norm(ao, (int64_t)h * dh, L.wo, (int64_t)h * dh, L.bo, nullptr, 0.f, cur, d, x1, d, B, d,
                              (int64_t)h * dh, stream))) return rc;
       const void* gin = x1;
-      if (!fold_norm) {
+      const void* gnorm = prescaled ? VY_NORM_PRESCALED : (fold_norm ? L.ln_post : nullptr);
+      if (!fold_norm && !prescaled) {
         if ((rc = vy_rmsnorm_fwd(x1, d, L.ln_post, n, d, B, d, p->eps, 1.0f, p->dtype, stream))) return rc;
         gin = n;
       }
-      if ((rc = vy_gemv_gated(gin, d, L.wgu, d, fold_norm ? L.ln_post : nullptr, p->eps, act, ffn, B, ffn, d, VY_ACT_GELU_TANH, stream))) return rc;
+      if ((rc = vy_gemv_gated(gin, d, L.wgu, d, gnorm, p->eps, act, ffn, B, ffn, d, VY_ACT_GELU_TANH, stream))) return rc;
       if ((rc = vy_gemv_norm(act, ffn, L.wdown, ffn, nullptr, nullptr, 0.f, x1, d, nxt, d, B, d, ffn, stream))) return rc;
       cur = nxt;
       continue;

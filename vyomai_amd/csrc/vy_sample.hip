@@ -6,6 +6,7 @@
 // elements in registers and the workgroup adds them in a fixed order -- no atomics, so the result
 // does not depend on scheduling.  The row is re-read from L2 for every pass (V = 50265 bf16 = 100 KB).
 #include "vy_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -113,6 +114,106 @@ __global__ __launch_bounds__(ST) void greedy_step_kernel(const T* __restrict__ l
       for (int w = 1; w < SW; ++w)
         if (bi[w] != 0x7fffffff && (i == 0x7fffffff || bv[w] > v || (bv[w] == v && bi[w] < i))) { v = bv[w]; i = bi[w]; }
       next = i == 0x7fffffff ? 0 : i;   // a row of NaNs has no maximum: token 0, not an out-of-range id
+      tokens[(int64_t)b * ldt + cur_pos] = next;
+    }
+    bool eos = eos_reached[b];
+    if (!forced)
+      for (int e = 0; e < n_eos; ++e) eos |= (next == eos_ids[e]);
+    eos_reached[b] = eos;
+    if (!eos && not_done) atomicAdd(not_done, 1);
+  }
+}
+
+// ---- two-stage top-1 for wide vocabularies ---------------------------------------------------------
+// One workgroup per row walks 100 KB (V = 50265) to 514 KB (V = 257216, one sequence) of logits: 13 / 35 us of a
+// decode step.  Here stage 1 spreads a row over chunks of 8192 logits (one 256-thread workgroup each, every load
+// issued before the first compare) and leaves a (value, index) candidate per chunk; stage 2 is greedy_step_kernel's
+// bookkeeping on <= 64 candidates per row.  Same order (value descending, index ascending; a row of NaNs -> 0).
+constexpr int GP_CHUNK = 8192, GP_MAXCH = 64, GP_MAXB = 256;
+__device__ float g_gp_v[GP_MAXB * GP_MAXCH];
+__device__ int g_gp_i[GP_MAXB * GP_MAXCH];
+
+__device__ __forceinline__ void gp_take(float v, int i, float& bv, int& bi) {
+  if (v > bv || (v == bv && i < bi) || bi == 0x7fffffff) { bv = v; bi = i; }
+}
+__device__ __forceinline__ void gp_merge(float ov, int oi, float& bv, int& bi) {
+  if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void greedy_part_kernel(const T* __restrict__ logits, int64_t ldl, int V, int nch,
+                                                          const uint8_t* __restrict__ text_mask, int64_t ldm, int64_t cur_pos) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (text_mask && text_mask[(int64_t)b * ldm + cur_pos]) return;   // forced position: stage 2 copies the prompt token
+  const T* row = logits + (int64_t)b * ldl;
+  const int lo = ch * GP_CHUNK, hi = min(V, lo + GP_CHUNK);
+  int best_i = 0x7fffffff;
+  float best_v = -INFINITY;
+  if constexpr (std::is_same<T, bf16>::value) {
+    if ((reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+      constexpr int CPT = GP_CHUNK / 8 / 256;   // 4 chunks of 8 per thread
+      bf16x8 c8[CPT];
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int e0 = lo + (u * 256 + tid) * 8;
+        c8[u] = *reinterpret_cast<const bf16x8*>(row + (e0 + 8 <= V ? e0 : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < CPT; ++u) {
+        const int e0 = lo + (u * 256 + tid) * 8;
+        if (e0 + 8 <= V) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gp_take((float)c8[u][e], e0 + e, best_v, best_i);
+        } else {
+          for (int e = e0; e < hi; ++e) gp_take(ldf(row, e), e, best_v, best_i);
+        }
+      }
+    } else {
+      for (int i = lo + tid; i < hi; i += 256) gp_take(ldf(row, i), i, best_v, best_i);
+    }
+  } else {
+    for (int i = lo + tid; i < hi; i += 256) gp_take(ldf(row, i), i, best_v, best_i);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best_v, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    gp_merge(ov, oi, best_v, best_i);
+  }
+  if (lane == 0) { bv[wave] = best_v; bi[wave] = best_i; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) gp_merge(bv[w], bi[w], best_v, best_i);
+    g_gp_v[b * GP_MAXCH + ch] = best_v;
+    g_gp_i[b * GP_MAXCH + ch] = best_i;
+  }
+}
+
+__global__ __launch_bounds__(64) void greedy_finish_kernel(int nch, int64_t* __restrict__ tokens, int64_t ldt, int64_t cur_pos,
+                                                           const uint8_t* __restrict__ text_mask, int64_t ldm,
+                                                           const int64_t* __restrict__ eos_ids, int n_eos,
+                                                           uint8_t* __restrict__ eos_reached, int32_t* __restrict__ not_done) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const bool forced = text_mask && text_mask[(int64_t)b * ldm + cur_pos];
+  float best_v = -INFINITY;
+  int best_i = 0x7fffffff;
+  if (!forced) {
+    if (lane < nch) { best_v = g_gp_v[b * GP_MAXCH + lane]; best_i = g_gp_i[b * GP_MAXCH + lane]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best_v, o, 64);
+      const int oi = __shfl_xor(best_i, o, 64);
+      gp_merge(ov, oi, best_v, best_i);
+    }
+  }
+  if (lane == 0) {
+    int64_t next;
+    if (forced) {
+      next = tokens[(int64_t)b * ldt + cur_pos];
+    } else {
+      next = best_i == 0x7fffffff ? 0 : best_i;
       tokens[(int64_t)b * ldt + cur_pos] = next;
     }
     bool eos = eos_reached[b];
@@ -234,6 +335,22 @@ extern "C" int vy_greedy_step(const void* logits, int64_t ldl, int64_t B, int64_
       n_eos < 0 || (n_eos > 0 && !eos_ids))
     VY_FAIL(VY_ERR_ARG, "vy_greedy_step: bad arguments");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "vy_greedy_step: bad dtype %d", dtype);
+  static const int two_stage = [] { const char* e = getenv("VY_GREEDY_TWO_STAGE"); return e ? atoi(e) : 1; }();
+  const int64_t nch = (V + GP_CHUNK - 1) / GP_CHUNK;
+  if (two_stage && V >= 2 * GP_CHUNK && nch <= GP_MAXCH && B <= GP_MAXB) {
+    const dim3 grid((unsigned)nch, (unsigned)B);
+    if (dtype == VY_BF16)
+      hipLaunchKernelGGL(greedy_part_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)logits, ldl, (int)V, (int)nch, text_mask,
+                         ldm, cur_pos);
+    else
+      hipLaunchKernelGGL(greedy_part_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, ldl, (int)V, (int)nch,
+                         text_mask, ldm, cur_pos);
+    hipLaunchKernelGGL(greedy_finish_kernel, dim3((unsigned)B), dim3(64), 0, st, (int)nch, tokens, ldt, cur_pos, text_mask, ldm,
+                       eos_ids, (int)n_eos, eos_reached, not_done);
+    VY_CHECK_LAUNCH("vy_greedy_step");
+    return VY_OK;
+  }
   if (dtype == VY_BF16)
     hipLaunchKernelGGL(greedy_step_kernel<bf16>, dim3((unsigned)B), dim3(ST), 0, st, (const bf16*)logits, ldl, (int)V, tokens,
                        ldt, cur_pos, text_mask, ldm, eos_ids, (int)n_eos, eos_reached, not_done);

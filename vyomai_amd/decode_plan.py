@@ -162,7 +162,9 @@ class VyGemmaPlan(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_layers", "B", "d", "h", "hk", "dh", "ffn", "vocab", "dtype")] + \
                [("eps", C.c_float), ("cos_tab", C.c_void_p), ("sin_tab", C.c_void_p),
                 ("layers", C.POINTER(VyGemmaLayer)), ("norm_w", C.c_void_p), ("head_w", C.c_void_p),
-                ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("flags", C.c_int32)]
+
+GEMMA_PRESCALED = 1
 
 
 class GemmaDecodePlan:
@@ -188,10 +190,18 @@ class GemmaDecodePlan:
 
         layers = list(model.layers)
         arr = (VyGemmaLayer * len(layers))()
+        # single-sequence bf16 decode: RMSNorm folded into the weights (VY_GEMMA_PRESCALE=0: separate RMSNorm launches)
+        prescale = dt == torch.bfloat16 and batch <= 4 and os.environ.get("VY_GEMMA_PRESCALE", "1") != "0"
         for i, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp
             wqkv, bqkv = _packed([a.q_proj, a.k_proj, a.v_proj], layer, "_qkv")
             wgu, _ = _packed([m.gate_proj, m.up_proj], m, "_gu")
+            if prescale:
+                # the norms' (1 + w) folded into the K axis of the weights that follow them (done once; the step then
+                # needs no RMSNorm launch: each product scales itself by the row's rsqrt(mean x^2 + eps))
+                with torch.no_grad():
+                    wqkv = (wqkv.float() * (1.0 + layer.input_layernorm.weight.detach().float())[None, :]).to(dt).contiguous()
+                    wgu = (wgu.float() * (1.0 + layer.post_attention_layernorm.weight.detach().float())[None, :]).to(dt).contiguous()
             kc, vc = caches[i]
             if kc.dtype != dt or kc.shape[0] < batch or kc.stride(3) != 1 or kc.stride() != vc.stride():
                 raise ValueError(f"cache buffers {tuple(kc.shape)} do not fit (B={batch})")
@@ -222,6 +232,7 @@ class GemmaDecodePlan:
         nbytes = lib.vy_gemma_ws_bytes(batch, p.d, p.h, p.dh, p.ffn, p.dtype)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         p.ws, p.ws_bytes = self.ws.data_ptr(), nbytes
+        p.flags = GEMMA_PRESCALED if prescale else 0
         self.plan, self.batch, self.d, self.dtype, self.device = p, batch, p.d, dt, dev
         self.ldv = (t.vocab_size + 7) // 8 * 8
         self.vocab = t.vocab_size
