@@ -643,6 +643,9 @@ int vy_attn_decode_ex(const void* q, int64_t q_sb, int64_t q_sh, const void* k, 
                       int64_t k_sl, const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl, void* out,
                       int64_t o_sb, int64_t B, int h, int hk, int64_t S, const int* pos_dev, int dh, float scale,
                       int dtype, void* stream);
+int vy_dec_attn(const void* q, int64_t q_sb, const void* k, const void* v, int64_t c_sb, int64_t c_sh, int64_t c_sl, void* out,
+                int64_t o_sb, int B, int h, int hk, int64_t S, int64_t smax, const int* pos_dev, int dh, float scale,
+                hipStream_t st);
 
 extern "C" int vy_attn_decode(const void* q, int64_t q_sb, int64_t q_sh, const void* k, int64_t k_sb,
                               int64_t k_sh, int64_t k_sl, const void* v, int64_t v_sb, int64_t v_sh,
@@ -657,6 +660,13 @@ int vy_attn_decode_ex(const void* q, int64_t q_sb, int64_t q_sh, const void* k, 
                       int64_t o_sb, int64_t B, int h, int hk, int64_t S, const int* pos_dev, int dh, float scale,
                       int dtype, void* stream) {
   const char* who = "vy_attn_decode";
+  // the resident-context kernel of vy_decode.hip (bf16, head widths 64 / 256, contexts up to 640 / 384 keys); under a
+  // graph the context length is read on the device and the cache capacity is not known here: S bounds it
+  if (dtype == VY_BF16 && q_sh == dh && k_sb == v_sb && k_sh == v_sh && k_sl == v_sl) {
+    const int rc = vy_dec_attn(q, q_sb, k, v, k_sb, k_sh, k_sl, out, o_sb, (int)B, h, hk, S, pos_dev ? k_sh / (k_sl ? k_sl : 1) : S,
+                               pos_dev, dh, scale, (hipStream_t)stream);
+    if (rc != VY_ERR_UNSUPPORTED) return rc;
+  }
   AttnParams p{};
   p.q = q; p.q_sb = q_sb; p.q_sh = q_sh; p.q_sl = (int64_t)h * dh;  // single token: unused stride
   p.k = k; p.k_sb = k_sb; p.k_sh = k_sh; p.k_sl = k_sl;

@@ -18,6 +18,7 @@
 // eager / graph / prefill comparisons in the tests hold unchanged.
 #include "vy_common.h"
 #include <stdlib.h>
+#include <float.h>
 
 namespace {
 
@@ -430,6 +431,138 @@ int dec_part64_go(DecGemmArgs a, int K, hipStream_t st) {
 //   GV_QKV: rotary embedding fused: the four waves of a workgroup take the columns {d, d+1, d+dh/2, d+1+dh/2} of one
 //         head and swap partners through LDS (rope2_kernel's arithmetic, vy_misc.hip)   (no RoPE launch)
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Single-query attention against the KV cache (reference models/decoder.py:107 / layers/attention.py with L = 1 and
+// mask = None): one workgroup per (batch row, query head), every K and V chunk of the row's context requested
+// BEFORE the first dot product (NP passes of NW * 64 / (DH / 8) keys: a compile-time count, no loop around the
+// loads), plain two-pass softmax over the scores held in registers (no online rescaling: the whole context is
+// resident), reductions on the DPP / permlane path, two barriers.  The general attn_rowwise_kernel walks the context in
+// dependent trips with ds_bpermute reductions: 11.9 us for the 8 x 300-key rows of a PaliGemma-shape step, 14.7 us for
+// 384 rows x 577 keys -- this one is bound by the K/V stream alone.
+//   lane = (key group g, 16-byte chunk ch of the head): LPK = DH / 8 lanes per key, KPW = 64 / LPK keys per wave pass.
+// ------------------------------------------------------------------------------------------
+struct DecAttnArgs {
+  const bf16* q; long long q_sb;            // q[b][head * DH + d]
+  const bf16* k; const bf16* v; long long c_sb, c_sh, c_sl;
+  bf16* out; long long o_sb;                // out[b][head * DH + d]
+  const int* pos_dev; int S; int h, hk; float scale;
+};
+
+template <int LPK>
+__device__ __forceinline__ float dec_group_sum(float v) {   // sum over the LPK lanes of a key group, in every lane
+  if constexpr (LPK == 8) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    return v;
+  } else {   // 32 lanes: a row of 16, then the neighbouring row
+    v = dec_row16_sum(v);
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
+  }
+}
+// sum over the lanes that hold the same chunk ch (stride LPK), in every lane
+template <int LPK>
+__device__ __forceinline__ float dec_stride_sum(float v) {
+  if constexpr (LPK == 8) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
+  }
+  const unsigned w = __builtin_bit_cast(unsigned, v);
+  auto s32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __builtin_bit_cast(float, (unsigned)s32[0]) + __builtin_bit_cast(float, (unsigned)s32[1]);
+}
+
+template <int DH, int NW, int NP>
+__global__ __launch_bounds__(64 * NW) void dec_attn_kernel(const DecAttnArgs p) {
+  constexpr int LPK = DH / 8, KPW = 64 / LPK, KPP = NW * KPW;
+  __shared__ float red_m[NW], red_l[NW];
+  __shared__ float red_o[NW][DH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int kvh = head / (p.h / p.hk);
+  const int g = lane / LPK, ch = lane % LPK;
+  const int S = p.pos_dev ? *p.pos_dev + 1 : p.S;
+  const bf16* kb = p.k + (long long)b * p.c_sb + (long long)kvh * p.c_sh + ch * 8;
+  const bf16* vb = p.v + (long long)b * p.c_sb + (long long)kvh * p.c_sh + ch * 8;
+  const bf16x8 q8 = *reinterpret_cast<const bf16x8*>(p.q + (long long)b * p.q_sb + head * DH + ch * 8);
+  bf16x8 kr[NP], vr[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int j = i * KPP + wave * KPW + g;
+    const long long jo = (long long)(j < S ? j : S - 1) * p.c_sl;
+    kr[i] = *reinterpret_cast<const bf16x8*>(kb + jo);
+    vr[i] = *reinterpret_cast<const bf16x8*>(vb + jo);
+  }
+  float qf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qf[e] = (float)q8[e];
+  float sc[NP];
+  float m = -FLT_MAX;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d = fmaf(qf[e], (float)kr[i][e], d);
+    d = dec_group_sum<LPK>(d) * p.scale;
+    const int j = i * KPP + wave * KPW + g;
+    sc[i] = j < S ? d : -FLT_MAX;
+    m = fmaxf(m, sc[i]);
+  }
+  m = dec_wave_max(m);
+  if (lane == 0) red_m[wave] = m;
+  __syncthreads();
+  float M = red_m[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) M = fmaxf(M, red_m[w]);
+  float l = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int j = i * KPP + wave * KPW + g;
+    const float ev = j < S ? __expf(sc[i] - M) : 0.f;
+    l += ev;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(ev, (float)vr[i][e], acc[e]);
+  }
+  // per wave: the weights of its keys (each key counted once: chunk 0 of its group) and, per chunk, the sum over
+  // the wave's key groups
+  l = dec_wave_sum(ch == 0 ? l : 0.f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = dec_stride_sum<LPK>(acc[e]);
+  if (lane == 0) red_l[wave] = l;
+  if (g == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red_o[wave][ch * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (tid < DH) {
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { L += red_l[w]; o += red_o[w][tid]; }
+    p.out[(long long)b * p.o_sb + head * DH + tid] = (bf16)(o / L);
+  }
+}
+
+template <int DH, int NW>
+int dec_attn_go(const DecAttnArgs& a, int B, int Smax, hipStream_t st) {
+  constexpr int KPP = NW * (64 / (DH / 8));
+  const dim3 grid((unsigned)a.h, (unsigned)B), block(64 * NW);
+  const int np = (Smax + KPP - 1) / KPP;
+  if (np <= 3) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 3>), grid, block, 0, st, a);
+  else if (np <= 5) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 5>), grid, block, 0, st, a);
+  else if (np <= 7) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 7>), grid, block, 0, st, a);
+  else if (np <= 10) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 10>), grid, block, 0, st, a);
+  else if (np <= 12) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 12>), grid, block, 0, st, a);
+  else return 1;
+  return 0;
+}
+
 enum { GV_PLAIN = 0, GV_GATED = 1, GV_QKV = 2 };
 struct DecGemvArgs {
   const bf16* x; const bf16* w; const bf16* bias; const bf16* residual; bf16* y;
@@ -675,5 +808,26 @@ int vy_dec_gemv1_qkv(const void* x, const void* w, const void* bias, void* q, vo
   a.nq = h * dh; a.nkv = hk * dh; a.dh = dh;
   if (prescaled ? dec_gemv1_go<GV_QKV, true>(a, st) : dec_gemv1_go<GV_QKV, false>(a, st)) return VY_ERR_UNSUPPORTED;
   VY_CHECK_LAUNCH("vy_dec_gemv1_qkv");
+  return VY_OK;
+}
+
+// single-query attention of the decode steps.  smax: an upper bound of the context length when it is read on the
+// device (pos_dev), else S.  Returns VY_ERR_UNSUPPORTED for shapes the resident-context kernel does not cover.
+int vy_dec_attn(const void* q, int64_t q_sb, const void* k, const void* v, int64_t c_sb, int64_t c_sh, int64_t c_sl, void* out,
+                int64_t o_sb, int B, int h, int hk, int64_t S, int64_t smax, const int* pos_dev, int dh, float scale,
+                hipStream_t st) {
+  static const int on = [] { const char* e = getenv("VY_DEC_ATTN"); return e ? atoi(e) : 1; }();
+  if (!on || (dh != 64 && dh != 256) || hk < 1 || h % hk || S < 1 || c_sl % 8 || c_sh % 8 || c_sb % 8 || q_sb % 8 ||
+      ((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)v % 16))
+    return VY_ERR_UNSUPPORTED;
+  DecAttnArgs a{};
+  a.q = (const bf16*)q; a.q_sb = q_sb; a.k = (const bf16*)k; a.v = (const bf16*)v; a.c_sb = c_sb; a.c_sh = c_sh; a.c_sl = c_sl;
+  a.out = (bf16*)out; a.o_sb = o_sb; a.pos_dev = pos_dev; a.S = (int)S; a.h = h; a.hk = hk; a.scale = scale;
+  const int bound = (int)(pos_dev ? smax : S);
+  int rc;
+  if (dh == 64) rc = dec_attn_go<64, 8>(a, B, bound, st);
+  else rc = dec_attn_go<256, 16>(a, B, bound, st);
+  if (rc) return VY_ERR_UNSUPPORTED;
+  VY_CHECK_LAUNCH("vy_dec_attn");
   return VY_OK;
 }
