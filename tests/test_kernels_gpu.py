@@ -171,6 +171,13 @@ ATTN_CASES = [
     (2, 2, 2, 64, 64, 128, False, 0, True, False),
     (2, 4, 2, 17, 17, 16, True, 0, True, False),   # row-wise kernel (dh 16)
     (3, 12, 12, 197, 197, 64, False, 0, False, False),  # ViT shape
+    # other head widths: the general MFMA kernel (bf16) / the row-wise kernel (fp32)
+    (1, 16, 16, 256, 256, 72, False, 0, False, False),   # SigLIP-So400m (Examples/paligemma.ipynb cell 9)
+    (2, 8, 1, 264, 264, 256, True, 0, False, False),     # Gemma-2B prefill, MQA (cell 12)
+    (2, 8, 1, 70, 110, 256, True, 40, True, False),      # chunked prefill with padding (left padding: dead rows)
+    (2, 3, 3, 100, 100, 96, False, 0, True, False),
+    (1, 2, 2, 130, 130, 160, True, 0, False, False),
+    (2, 4, 2, 33, 33, 72, True, 0, True, False),
 ]
 
 

@@ -375,6 +375,205 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
     p.lse[((int64_t)b * p.h + head) * p.L + qi] = (m_run + log2f(l_tot)) * LN2;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// MFMA flash forward for the other head widths (bf16): SigLIP's 72 (run as 96: the missing columns are zeros in
+// LDS and never stored) and Gemma's 256 -- the PaliGemma-shape prefill (reference Examples/paligemma.ipynb cells
+// 9, 12) -- and anything else up to 256 that is a multiple of 8.  Not the tuned structure of attn_fwd_mfma_kernel
+// (these launches are 16 x 256 x 256 and 8 x 264 x 264 problems): register-staged K/V tiles of 64 keys, one tile in
+// LDS at a time, 64 query rows per workgroup (16 per wave), mfma_f32_16x16x32_bf16 throughout.
+//   * swapped QK^T: A = 16 keys, B = the wave's 16 query rows -> a lane owns ONE query row (lane & 15) and, per
+//     16-key block, the 4 consecutive keys 4 * (lane >> 4) .. + 3: the softmax of a row is 16 register values and
+//     three lane-group exchanges;
+//   * P stays in registers as the B operand of O^T = V^T P^T: a k-step of 32 keys takes the lane's 4 + 4 values of
+//     two key blocks, i.e. the contraction index is walked in the order the scores already sit in -- and V^T's
+//     fragments are read in the same order by two transposing LDS reads (ds_read_b64_tr_b16) of the row-major tile.
+// Masks: causal (+ start_pos) and key padding as in attn_fwd_mfma_kernel, rows without a visible key get the
+// reference's uniform average; a dense additive mask goes to the row-wise kernel.
+// ------------------------------------------------------------------------------------------
+template <int DHP>
+__global__ __launch_bounds__(256) void attn_fwd_gen_kernel(AttnParams p, int dh) {
+  constexpr int PITCH = (DHP + 8) * 2;       // bytes per LDS row (16 B of padding: conflict-free fragment reads)
+  constexpr int KS = DHP / 32;               // k-steps of QK^T
+  constexpr int NDB = DHP / 16;              // 16-wide d blocks of O^T
+  constexpr int CPRW = DHP / 8;              // 16-byte chunks per row
+  constexpr int CPT = 64 * CPRW / 256;       // chunks per thread and tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * PITCH];
+  char* kt = smem;
+  char* vt = smem + 64 * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int head = (int)blockIdx.y % p.h, b = (int)blockIdx.y / p.h;
+  const int kvh = head / (p.h / p.hk);
+  const int q0 = (int)blockIdx.x * 64;
+  const int qi = q0 + wave * 16 + r16;
+  const int qrow = qi < p.L ? qi : p.L - 1;
+  const bf16* Q = (const bf16*)p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qrow * p.q_sl;
+  const bf16* Kb = (const bf16*)p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
+  const bf16* Vb = (const bf16*)p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const uint8_t* kp = haskp ? p.keypad + (int64_t)b * p.kp_sb : nullptr;
+  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int d0 = 32 * ks + 8 * kq;
+    qf[ks] = d0 < dh ? *reinterpret_cast<const bf16x8*>(Q + d0) : zero8;
+  }
+  f32x4 o[NDB];
+#pragma unroll
+  for (int n = 0; n < NDB; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -FLT_MAX, l_run = 0.f;
+  const float c = p.scale * LOG2E;
+  int nt = (p.S + 63) / 64;
+  if (causal) {
+    const int kv_end = min(p.S, p.start_pos + q0 + 64);
+    nt = max(1, (kv_end + 63) / 64);
+  }
+  // transposing-read addresses of the V tile: lane j of a 16-lane group supplies row (j >> 2), columns 4 (j & 3) ..
+  const unsigned vtr = vy_lds_addr(vt) + (4 * kq + (r16 >> 2)) * PITCH + (4 * (r16 & 3)) * 2;
+
+  for (int t = 0; t < nt; ++t) {
+    const int k0 = t * 64;
+    // stage the tile: 16-byte chunks, zero beyond the head width and beyond the last key
+    bf16x8 kreg[CPT], vreg[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int cidx = tid + 256 * i;
+      const int row = cidx / CPRW, ch = cidx - row * CPRW;
+      const int kj = k0 + row;
+      const bool ok = ch * 8 < dh && kj < p.S;
+      const int64_t kjc = kj < p.S ? kj : p.S - 1;
+      kreg[i] = ok ? *reinterpret_cast<const bf16x8*>(Kb + kjc * p.k_sl + (ch * 8 < dh ? ch * 8 : 0)) : zero8;
+      vreg[i] = ok ? *reinterpret_cast<const bf16x8*>(Vb + kjc * p.v_sl + (ch * 8 < dh ? ch * 8 : 0)) : zero8;
+    }
+    __syncthreads();   // the previous tile's fragments have been read
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const int cidx = tid + 256 * i;
+      const int row = cidx / CPRW, ch = cidx - row * CPRW;
+      *reinterpret_cast<bf16x8*>(kt + row * PITCH + ch * 16) = kreg[i];
+      *reinterpret_cast<bf16x8*>(vt + row * PITCH + ch * 16) = vreg[i];
+    }
+    __syncthreads();
+    // S^T = K Q^T: four 16-key blocks
+    f32x4 sc[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      sc[blk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (16 * blk + r16) * PITCH + (32 * ks + 8 * kq) * 2);
+        sc[blk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc[blk], 0, 0, 0);
+      }
+    }
+    // masks: register r of block blk is key k0 + 16 blk + 4 kq + r
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = k0 + 16 * blk + 4 * kq + r;
+        bool vis = kj < p.S;
+        if (causal) vis = vis && kj <= qi + p.start_pos;
+        if (haskp) vis = vis && kp[kj < p.S ? kj : 0] != 0;
+        const float tv = vis ? sc[blk][r] : -INFINITY;
+        sc[blk][r] = tv;
+        tmax = fmaxf(tmax, tv);
+      }
+    // the row's keys are spread over the four lane groups (lane >> 4)
+    {
+      const unsigned u = __builtin_bit_cast(unsigned, tmax);
+      auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+      tmax = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+      const unsigned w = __builtin_bit_cast(unsigned, tmax);
+      auto s32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+      tmax = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+    }
+    const float m_new = fmaxf(m_run, tmax * c);   // (-inf * c stays -inf; m_run is finite)
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    l_run *= alpha;
+#pragma unroll
+    for (int n = 0; n < NDB; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[n][r] *= alpha;
+    float rs = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sc[blk][r], c, -m_run));
+        sc[blk][r] = e;
+        rs += e;
+      }
+    l_run += rs;   // this lane group's keys only; the four groups are added at the end
+    // O^T += V^T P^T, k-steps of 32 keys = blocks (2 tt, 2 tt + 1) in the order the scores sit in
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      bf16x8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pf[r] = (bf16)sc[2 * tt][r]; pf[4 + r] = (bf16)sc[2 * tt + 1][r]; }
+      vy_static_for<NDB>([&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+        u.h.a = vy_lds_tr16_off<n * 32>(vtr + (32 * tt) * PITCH);
+        u.h.b = vy_lds_tr16_off<n * 32>(vtr + (32 * tt + 16) * PITCH);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        vy_tie(u.v);
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf, o[n], 0, 0, 0);
+      });
+    }
+  }
+  // row totals over the four lane groups
+  float l_tot = l_run;
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, l_tot);
+    auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    l_tot = __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, l_tot);
+    auto s32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    l_tot = __builtin_bit_cast(float, (unsigned)s32[0]) + __builtin_bit_cast(float, (unsigned)s32[1]);
+  }
+  if (haskp && l_tot == 0.f) {
+    // no visible key: the reference's softmax over [finfo.min, ...] is uniform over EVERY key -> the column mean of
+    // V (rare: a plain walk over the keys for this lane's columns d = 16 n + 4 kq + r)
+#pragma unroll
+    for (int n = 0; n < NDB; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kj = 0; kj < p.S; ++kj) {
+#pragma unroll
+      for (int n = 0; n < NDB; ++n) {
+        const int d0 = 16 * n + 4 * kq;
+        if (d0 < dh) {
+          const bf16x4 v4 = *reinterpret_cast<const bf16x4*>(Vb + (int64_t)kj * p.v_sl + d0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[n][r] += (float)v4[r];
+        }
+      }
+    }
+    l_tot = (float)p.S;
+    m_run = -FLT_MAX;
+  }
+  const float inv = 1.0f / l_tot;
+  if (qi < p.L) {
+    bf16* orow = (bf16*)p.out + (int64_t)b * p.o_sb + (int64_t)qi * p.o_sl + head * dh;
+#pragma unroll
+    for (int n = 0; n < NDB; ++n) {
+      const int d0 = 16 * n + 4 * kq;
+      if (d0 < dh) {
+        bf16x4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = (bf16)(o[n][r] * inv);
+        *reinterpret_cast<bf16x4*>(orow + d0) = w;
+      }
+    }
+    if (p.lse && kq == 0) p.lse[((int64_t)b * p.h + head) * p.L + qi] = (m_run + log2f(l_tot)) * LN2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // row-wise kernel: f32 parity path, unusual head dims, and decode (L == 1)
 // one workgroup (4 waves) per (b, head, query row).  CPR lanes share one key row (16 B each).
@@ -632,6 +831,15 @@ extern "C" int vy_attn_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
     const dim3 grid((unsigned)(h * B), (unsigned)((L + 127) / 128), 1), block(256);
     if (dh == 64) hipLaunchKernelGGL(attn_fwd_mfma_kernel<64>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_mfma_kernel<128>, grid, block, 0, st, p);
+    VY_CHECK_LAUNCH(who);
+    return VY_OK;
+  }
+  static const int gen_on = [] { const char* e = getenv("VY_ATTN_GEN"); return e ? atoi(e) : 1; }();
+  if (gen_on && dtype == VY_BF16 && L > 1 && dh % 8 == 0 && dh <= 256 && !(mask_kind & VY_MASK_ADDITIVE)) {
+    // other head widths (72 -> 96 columns, ... 256): the general MFMA kernel, 64 query rows per workgroup
+    const dim3 grid((unsigned)((L + 63) / 64), (unsigned)(h * B), 1), block(256);
+    if (dh <= 96) hipLaunchKernelGGL(attn_fwd_gen_kernel<96>, grid, block, 0, st, p, dh);
+    else hipLaunchKernelGGL(attn_fwd_gen_kernel<256>, grid, block, 0, st, p, dh);
     VY_CHECK_LAUNCH(who);
     return VY_OK;
   }
