@@ -34,6 +34,11 @@ typedef enum {
 } vy_status;
 
 typedef enum { VY_ACT_NONE = 0, VY_ACT_GELU_ERF = 1, VY_ACT_GELU_TANH = 2 } vy_act;
+/* OR-ed into `act` of vy_linear_fwd / vy_linear_dgrad (training): the tensor saved for backward is act'(x W^T + b)
+ * instead of the pre-activation -- the forward epilogue has Phi and the Gaussian of the erf GELU at hand anyway, and
+ * the dgrad epilogue (dX = (dY W) * act') becomes one multiply per element instead of an erf + exp evaluation.
+ * vy_linear_fwd: pre_out receives act' (rounded to the storage type); vy_linear_dgrad: `pre` holds act'. */
+#define VY_ACT_SAVE_DERIV 0x100
 
 /* attention mask descriptor bits (vy_attn_fwd / vy_attn_bwd) */
 enum {

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("VY_LIB_PATH") or os.path.join(_HERE, "lib", "libvyom_
 
 VY_F32, VY_BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH = 0, 1, 2
+ACT_SAVE_DERIV = 0x100   # saved tensor = act'(pre) instead of pre (include/vyom_hip.h)
 MASK_NONE, MASK_CAUSAL, MASK_KEYPAD, MASK_ADDITIVE = 0, 1, 2, 4
 
 _p, _i64, _i, _f, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64

@@ -19,7 +19,7 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import ACT_GELU_ERF, ACT_NONE, VyomHipError
 from .layers.attention import _shadow
 from .layers.mask import AttnMask
@@ -315,7 +315,8 @@ class FfnBlockFn(torch.autograd.Function):
         dt = x.dtype
         pre = torch.empty((*x.shape[:-1], w1.shape[0]), dtype=dt, device=x.device)
         hmid = torch.empty_like(pre)
-        ops.linear(x, _shadow(w1, dt), _shadow(b1, dt), act=act, pre_out=pre, out=hmid)
+        # `pre` holds act'(x W1^T + b1), not the pre-activation: the backward multiplies by it directly
+        ops.linear(x, _shadow(w1, dt), _shadow(b1, dt), act=act | _lib.ACT_SAVE_DERIV, pre_out=pre, out=hmid)
         s = ops.linear(hmid, _shadow(w2, dt), _shadow(b2, dt), residual=residual, dropout=drop)
         ctx.drop = drop
         y, mean, rstd = ops.layernorm(s, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
@@ -333,7 +334,7 @@ class FfnBlockFn(torch.autograd.Function):
         dy = dy.contiguous()
         ds, dg, dbt = _ln_bwd(dy, s, ln_w, ln_b, mean, rstd)
         dz = ops.dropout(ds, *ctx.drop) if ctx.drop is not None else ds   # the forward's mask (see above)
-        dpre = ops.linear_dgrad(dz, _wt(w2, dt), pre=pre, act=ctx.act)  # (dz W2) * act'(pre)
+        dpre = ops.linear_dgrad(dz, _wt(w2, dt), pre=pre, act=ctx.act | _lib.ACT_SAVE_DERIV)  # (dz W2) * act'(pre), act' saved
         dw2, db2 = _wgrad(dz, hmid, w2, b2)
         dx = ops.linear_dgrad(dpre, _wt(w1, dt))
         dw1, db1 = _wgrad(dpre, x, w1, b1)

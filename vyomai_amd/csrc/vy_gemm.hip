@@ -75,6 +75,7 @@ struct EpiPlain {
   int vec_ok;  // all row strides % 4 == 0 and base pointers 4-element aligned
   VyDrop drop; // dropout on act(x W^T + b) before the residual add (thr == 0: none)
   int wt_store; // large outputs: write-through (sc1) stores from the staged epilogue
+  int pre_deriv; // VY_ACT_SAVE_DERIV: `pre` receives act'(x W^T + b) / `gradpre` already holds act' (see include/vyom_hip.h)
 };
 
 template <typename T, int ACT, bool GRAD>
@@ -86,7 +87,13 @@ __device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[
     if (e.bias) { float b[4]; Quad<T>::load(e.bias + n, b);
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += b[i]; }
-    if (e.pre) Quad<T>::store(e.pre + m * e.ldy + n, v);
+    if (e.pre) {
+      if (e.pre_deriv) { float dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dv[i] = vy_act_grad<ACT>(round_like<T>(v[i]));
+        Quad<T>::store(e.pre + m * e.ldy + n, dv);
+      } else Quad<T>::store(e.pre + m * e.ldy + n, v);
+    }
     if constexpr (!GRAD) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = vy_act_fwd<ACT>(v[i]);
@@ -99,7 +106,7 @@ __device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[
     } else {
       if (e.gradpre) { float g[4]; Quad<T>::load(e.gradpre + m * e.ldg + n, g);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] *= vy_act_grad<ACT>(g[i]); }
+        for (int i = 0; i < 4; ++i) v[i] *= e.pre_deriv ? g[i] : vy_act_grad<ACT>(g[i]); }
     }
     if (e.residual) { float r[4]; Quad<T>::load(e.residual + m * e.ldr + n, r);
 #pragma unroll
@@ -114,7 +121,7 @@ __device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[
       if (n + i >= N) break;
       float x = v[i];
       if (e.bias) x += VyT<T>::ld(e.bias + n + i);
-      if (e.pre) VyT<T>::st(e.pre + m * e.ldy + n + i, x);
+      if (e.pre) VyT<T>::st(e.pre + m * e.ldy + n + i, e.pre_deriv ? vy_act_grad<ACT>(round_like<T>(x)) : x);
       if constexpr (!GRAD) {
         x = vy_act_fwd<ACT>(x);
         if (e.drop.thr) {
@@ -123,7 +130,7 @@ __device__ __forceinline__ void epi_plain_quad(const EpiPlain<T>& e, float (&v)[
           x = vy_drop_keep(e.drop, lots, (n + i) & 7) ? round_like<T>(x) * e.drop.scale : 0.f;
         }
       }
-      else if (e.gradpre) x *= vy_act_grad<ACT>(VyT<T>::ld(e.gradpre + m * e.ldg + n + i));
+      else if (e.gradpre) { const float gg = VyT<T>::ld(e.gradpre + m * e.ldg + n + i); x *= e.pre_deriv ? gg : vy_act_grad<ACT>(gg); }
       if (e.residual) x += VyT<T>::ld(e.residual + m * e.ldr + n + i);
       if (e.residual2) x += VyT<T>::ld(e.residual2 + m * e.ldr2 + n + i);
       VyT<T>::st(e.y + m * e.ldy + n + i, x);
@@ -360,7 +367,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)sv[e];
-        if (dual) {
+        if (dual && !ep.pre_deriv) {
           if (ep.vec_ok && n + 8 <= N) {
             *reinterpret_cast<bf16x8*>(ep.pre + m * ep.ldy + n) = sv;
           } else {
@@ -368,8 +375,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
           }
         }
         if constexpr (!GRAD && ACT != VY_ACT_NONE) {
+          if (dual && ep.pre_deriv) {
+            // the derivative is saved instead of the pre-activation: for the erf GELU both come out of one
+            // evaluation of Phi and the Gaussian (vy_phi_fast), so the backward epilogue is one multiply per element
+            bf16x8 d8;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = vy_act_fwd_fast<ACT>(v[e]);
+            for (int e = 0; e < 8; ++e) {
+              if constexpr (ACT == VY_ACT_GELU_ERF) {
+                float cdf, gs;
+                vy_phi_fast(v[e], cdf, gs);
+                d8[e] = (bf16)(cdf + v[e] * 0.39894228040143267794f * gs);
+                v[e] = v[e] * cdf;
+              } else {
+                d8[e] = (bf16)vy_act_grad_fast<ACT>(v[e]);
+                v[e] = vy_act_fwd_fast<ACT>(v[e]);
+              }
+            }
+            if (ep.vec_ok && n + 8 <= N) {
+              *reinterpret_cast<bf16x8*>(ep.pre + m * ep.ldy + n) = d8;
+            } else {
+              for (int e = 0; e < 8 && n + e < N; ++e) ep.pre[m * ep.ldy + n + e] = d8[e];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = vy_act_fwd_fast<ACT>(v[e]);
+          }
         }
         if constexpr (!GRAD) {
           if (ep.drop.thr) {   // n is a multiple of 8: one Philox call covers the chunk
@@ -384,7 +414,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
             if (ep.gradpre) {
               const bf16x8 g = pf ? p8 : *reinterpret_cast<const bf16x8*>(ep.gradpre + m * ep.ldg + n);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= vy_act_grad_fast<ACT>((float)g[e]);
+              for (int e = 0; e < 8; ++e) v[e] *= ep.pre_deriv ? (float)g[e] : vy_act_grad_fast<ACT>((float)g[e]);
             }
           }
           if (ep.residual) {
@@ -411,7 +441,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
           for (int e = 0; e < 8 && n + e < N; ++e) {
             float x = v[e];
             if constexpr (GRAD) {
-              if (ep.gradpre) x *= vy_act_grad_fast<ACT>((float)ep.gradpre[m * ep.ldg + n + e]);
+              if (ep.gradpre) { const float gg = (float)ep.gradpre[m * ep.ldg + n + e]; x *= ep.pre_deriv ? gg : vy_act_grad_fast<ACT>(gg); }
             }
             if (ep.residual) x += (float)ep.residual[m * ep.ldr + n + e];
             if (ep.residual2) x += (float)ep.residual2[m * ep.ldr2 + n + e];
@@ -2178,7 +2208,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
       ep.y[m * ep.ldy + n] = (bf16)x;
     } else if constexpr (EPI == 0) {
       if (ep.bias) x += (float)ep.bias[n];
-      if (ep.pre) ep.pre[m * ep.ldy + n] = (bf16)x;
+      if (ep.pre) ep.pre[m * ep.ldy + n] = (bf16)(ep.pre_deriv ? vy_act_grad<ACT>(vy_round_bf16(x)) : x);
       x = vy_act_fwd<ACT>(x);
       if (ep.drop.thr) {
         uint32_t lots[4];
@@ -2352,6 +2382,8 @@ int linear_impl(const void* x, int64_t ldx, const void* w, int64_t ldw, const vo
   if (!y) VY_FAIL(VY_ERR_ARG, "%s: null output", who);
   if (ldy < N) VY_FAIL(VY_ERR_ARG, "%s: ldy < N", who);
   EpiPlain<T> ep;
+  ep.pre_deriv = (act & VY_ACT_SAVE_DERIV) ? 1 : 0;
+  act &= ~VY_ACT_SAVE_DERIV;
   ep.bias = (const T*)bias; ep.residual = (const T*)residual; ep.ldr = ldr;
   ep.residual2 = (const T*)residual2; ep.ldr2 = ldr2;
   if (residual2 && !residual) VY_FAIL(VY_ERR_ARG, "%s: add_to2 without add_to", who);
