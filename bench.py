@@ -342,8 +342,9 @@ def main():
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                 "frac": round((wbytes + kvbytes) / per_tok * 1e-9 / PEAK_HBM_GBS, 4),
                                 "bytes_per_step": int(wbytes + kvbytes),
-                                "note": "algorithmic bytes: weights once (249 MB) + K/V of the mean context; ~88 dependent "
-                                        "launches per step, each bound by its own latency, not by bandwidth (DESIGN section 3)"}}
+                                "note": "algorithmic bytes: weights once (249 MB) + K/V of the mean context; 7 dependent launches per "
+                                        "layer, each ~1.3 us of boundary + 2-3 us until its loads have arrived; only the attention "
+                                        "launch (57 MB of K/V per layer) is bandwidth-bound (DESIGN section 3, round 2 second half)"}}
         model.train()
 
     roof = cpu = None

@@ -20,6 +20,7 @@ def stats(sub, name):
 stats("roofline", "roofline_probe")
 stats("decode", "decode")
 stats("bench", "bench")
+stats("paligemma", "paligemma_decode")
 dirs = [os.path.join(src, d) for d in ("pmc_fetch", "pmc_write", "pmc_hit")]
 if all(os.path.isdir(d) for d in dirs):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_pmc_json.py")] + dirs, capture_output=True, text=True)
@@ -28,9 +29,14 @@ if all(os.path.isdir(d) for d in dirs):
         print("wrote", f"{R}_gemm_pmc.json")
     else:
         print(out.stderr[-2000:])
-for log in ("roofline.log", "decode.log"):
+tl = os.path.join(src, "decode_timeline.log")
+if os.path.exists(tl):
+    keep = [l for l in open(tl).read().splitlines() if l[:1] in " lf" and ("|" in l or "stamped" in l)]
+    open(os.path.join(dst, f"{R}_decode_timeline.txt"), "w").write("\n".join(keep) + "\n")
+    print("wrote", f"{R}_decode_timeline.txt")
+for log in ("roofline.log", "decode.log", "paligemma.log"):
     p = os.path.join(src, log)
     if os.path.exists(p):
-        lines = [l for l in open(p).read().splitlines() if l.startswith(("{", "decode step"))]
+        lines = [l for l in open(p).read().splitlines() if l.startswith(("{", "decode step", "PaliGemma shape"))]
         if lines:
             open(os.path.join(dst, f"{R}_{log.replace('.log', '')}_run.txt"), "w").write("\n".join(lines) + "\n")

@@ -58,9 +58,10 @@ for l in range(NL):
     if t_first is None:
         t_first = st
     gap = (st - prev_end) / 100.0 if prev_end is not None else 0.0
-    med = np.median(rows[:, 1:5] - rows[:, 0:1], axis=0) / 100.0
-    ma = np.median(rows[:, 5] - rows[:, 0]) / 100.0
-    mb = np.median(rows[:, 6] - rows[:, 0]) / 100.0 if rows[:, 6].max() > 0 else float("nan")
+    def rel(col):   # median over the workgroups of (stamp - start); a kernel that has no such stamp leaves 0 there
+        return np.median(rows[:, col] - rows[:, 0]) / 100.0 if rows[:, col].max() > 0 else float("nan")
+    med = [rel(c_) for c_ in (1, 2, 3, 4)]
+    ma, mb = rel(5), rel(6)
     print(f"{l:4d}  {len(rows):4d}  {gap:7.2f} | {ma:5.2f} {mb:5.2f} {med[0]:6.2f} {med[1]:8.2f} {med[2]:8.2f} {med[3]:6.2f} | "
           f"{(en - st) / 100.0:7.2f}  {(rows[:, 0].max() - st) / 100.0:6.2f}")
     prev_end = en

@@ -18,5 +18,9 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_hit -o p -- python3 $ROOT/t
 echo "pmc passes done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/decode -o dec -- python3 $ROOT/tools/bench_decode_step.py --iters 20 > $OUT/decode.log 2>&1
 echo "decode step traced"
+python3 $ROOT/tools/decode_timeline.py --layers 12 > $OUT/decode_timeline.log 2>&1
+echo "decode timeline written"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/paligemma -o pg -- python3 $ROOT/tools/bench_paligemma.py > $OUT/paligemma.log 2>&1
+echo "configs[4] decode traced"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o b -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/bench.log 2>&1
 echo "bench traced"
