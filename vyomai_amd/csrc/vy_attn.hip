@@ -47,7 +47,7 @@ struct AttnParams {
 // MFMA flash forward (bf16)
 // ------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, DH == 64 ? 3 : 1) void attn_fwd_mfma_kernel(AttnParams p) {
   constexpr int RB = DH * 2;            // bytes per K/V row
   constexpr int TILE = 64 * RB;         // bytes per 64-key tile
   constexpr int NP = TILE / 1024 / 4;   // 1-KiB LDS-DMA pieces per wave per tile

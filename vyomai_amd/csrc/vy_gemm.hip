@@ -1029,7 +1029,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pipe_kernel(
     const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
     const int64_t m = pm0 + wm * 32 * TM + j * 32 + fr;
     const int n = pn0 + wn * 32 * TN + i * 32 + 16 * hq + 8 * fh;
-    *reinterpret_cast<u32x4*>(ep.y + m * ep.ldy + n) = o;
+    if (n + 8 <= N) {
+      *reinterpret_cast<u32x4*>(ep.y + m * ep.ldy + n) = o;   // (write-through here measured 15-25 % slower)
+    } else if (n < N) {   // the ragged end of the last column tile
+      const bf16x8 o8 = __builtin_bit_cast(bf16x8, o);
+      for (int e = 0; e < 8 && n + e < N; ++e) ep.y[m * ep.ldy + n + e] = o8[e];
+    }
   };
 
   for (int b = blockIdx.x; b < tiles_total; b += gridDim.x) {
@@ -1043,10 +1048,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pipe_kernel(
       const int R = (wave + NW * t) * 8 + lrow;
       xsrc[t] = X + (int64_t)(m0 + R) * ldx + (slot ^ ((R >> 1) & 7)) * 8;
     }
+    // the last column tile may reach beyond N (ragged widths, e.g. a vocabulary): rows of W that do not exist are read
+    // from 16 zero bytes, so the columns beyond N come out as the bias guard's 0 and are never stored
+    const bool ntail = n0 + BN > N;   // workgroup-uniform
+    int64_t wstep[GW];
 #pragma unroll
     for (int t = 0; t < GW; ++t) {
       const int R = (wave + NW * t) * 8 + lrow;
-      wsrc[t] = W + (int64_t)(n0 + R) * ldw + (slot ^ ((R >> 1) & 7)) * 8;
+      const bool ok = n0 + R < N;
+      wsrc[t] = ok ? W + (int64_t)(n0 + R) * ldw + (slot ^ ((R >> 1) & 7)) * 8 : reinterpret_cast<const bf16*>(vy_zero16);
+      wstep[t] = ok ? BK : 0;
     }
     auto stage_x = [&](int kt) {
       char* xb = smem + (kt % 3) * XT;
@@ -1058,7 +1069,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pipe_kernel(
       char* wb = smem + WOFF + (kt & 1) * WT;
 #pragma unroll
       for (int t = 0; t < GW; ++t)
-        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(wsrc[t] + kt * BK), (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(wsrc[t] + (ntail ? kt * wstep[t] : (int64_t)kt * BK)),
+                                         (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
     };
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -1150,9 +1162,15 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pipe_kernel(
         for (int rg = 0; rg < 4; ++rg) {
           float bq[4] = {0.f, 0.f, 0.f, 0.f};
           if (biasp) {
-            const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(biasp + n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh);
+            const int nb_ = n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh;
+            if (nb_ + 3 < N && ((reinterpret_cast<uintptr_t>(biasp + nb_) & 7) == 0)) {
+              const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(biasp + nb_);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bq[e] = (float)b4[e];
+              for (int e = 0; e < 4; ++e) bq[e] = (float)b4[e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bq[e] = nb_ + e < N ? (float)biasp[nb_ + e] : 0.f;
+            }
           }
 #pragma unroll
           for (int j = 0; j < TM; ++j) {
@@ -2283,14 +2301,19 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     int pipe_on = pipe_env;
     if (var == 31) { var = 14; pipe_on = 0; }   // the default selection without the pipelined kernel (A/B runs, tests)
     if constexpr (EPI == 0 && !GRAD) {
-      const int64_t tiles = (M / 256) * (N / 192);
-      if ((var == 14 || var == 30) && pipe_on && M % 256 == 0 && N % 192 == 0 && K % 64 == 0 && K >= 768 &&
-          tiles >= 2 * 256 && !ep.residual && !ep.residual2 && !ep.drop.thr && ep.vec_ok && !ep.pre &&
-          (N < 3072 || var == 30)) {   // (N >= 3072 keeps the 256 x 256 tiles: fewer operand bytes per FLOP)
+      const int64_t tiles_n192 = vy_cdiv(N, 192);
+      const int64_t tiles = (M / 256) * tiles_n192;
+      // N < 3072: the layer projections.  Wider outputs keep the one-shot 256 x 256 tiles (fewer operand bytes per FLOP);
+      // the persistent kernel takes ragged widths too (var 30 / VY_GEMM_PIPE_WIDE=1 force it: on the vocabulary
+      // projection, 65 tiles per CU, it measured 2.15-2.25 ms against 1.66-1.72 ms -- tools/bench_lmhead.py)
+      static const int pipe_wide = [] { const char* e = getenv("VY_GEMM_PIPE_WIDE"); return e ? atoi(e) : 0; }();
+      const bool wide_ok = var == 30 || (pipe_wide && N >= 8192);
+      if ((var == 14 || var == 30) && pipe_on && M % 256 == 0 && (N % 192 == 0 || wide_ok) && K % 64 == 0 && K >= 768 &&
+          tiles >= 2 * 256 && !ep.residual && !ep.residual2 && !ep.drop.thr && ep.vec_ok && !ep.pre && (N < 3072 || wide_ok)) {
         static const int pipe_knob = [] { const char* e = getenv("VY_GEMM_PIPE_KNOB"); return e ? atoi(e) : 0; }();
         const int g = (int)(tiles < 256 ? tiles : 256);
         hipLaunchKernelGGL((gemm_nt_bf16_pipe_kernel<ACT>), dim3(g), dim3(512), 0, st, X, ldx, W, ldw, (int)M, (int)N,
-                           (int)K, (int)(N / 192), (int)tiles, ep, pipe_knob);
+                           (int)K, (int)tiles_n192, (int)tiles, ep, pipe_knob);
         return 0;
       }
     }
