@@ -399,7 +399,7 @@ __device__ __forceinline__ unsigned long long range_bits64(int lo, int hi) {
 // ---- dq kernel: forward structure, no online softmax --------------------------------------
 // K/V tiles of 64 keys run through a 3-deep LDS-DMA ring with counted vmcnt waits (as in the
 // forward kernel); masks are per-lane bit words, P is recomputed as exp2(fma(s, c, -lse*log2e)).
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(BwdParams p) {
   constexpr int DH = 64, RB = 128, TILE = 64 * RB, NS = 3, KPW = 256;
   __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE + KPW * 8];  // K ring, V ring, key-padding words
   const int tid = threadIdx.x, lane = tid & 63;
@@ -506,45 +506,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdParams p) {
     if (causal && k0 > p.start_pos + wave_last) return;
     const char* kb_ = smem + buf * TILE;
     const char* vb_ = smem + (NS + buf) * TILE;
-    f32x16 st[2], dp[2];
+    unsigned long long vis = ~0ull;
+    if (haskp) vis = kpbits[tile];
+    const bool need_mask = (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first) || vis != ~0ull;
+    // key of register r: k0 + 4fh + kofs, kofs = 32kb + (r&3) + 8(r>>2); visible iff kofs <= klim
+    int klim = p.S - 1 - k0 - 4 * fh;
+    if (causal) klim = min(klim, qi + p.start_pos - k0 - 4 * fh);
+    const unsigned long long lm = need_mask ? (range_bits64(0, klim + 1) & (vis >> (4 * fh))) : ~0ull;
+    const unsigned lmw[2] = {(unsigned)lm, (unsigned)(lm >> 32)};
+    // one 32-key block at a time: scores and dP of a block are turned into dS (8 registers) before the next block's
+    // accumulators exist -- both blocks' st / dp tiles live at once cost 32 more registers, the difference between two
+    // and three waves per SIMD
+    bf16x8 ds[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      f32x16 st, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[kb][r] = 0.f; dp[kb][r] = neg_delta; }
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = neg_delta; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ k_sw) << 4));
         const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ v_sw) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
-        dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], dp[kb], 0, 0, 0);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], dp, 0, 0, 0);
       }
-    }
-    unsigned long long vis = ~0ull;
-    if (haskp) vis = kpbits[tile];
-    const bool need_mask = (k0 + 64 > p.S) || (causal && k0 + 63 > p.start_pos + wave_first) || vis != ~0ull;
-    bf16x8 ds[2][2];
-    if (need_mask) {
-      // key of register r: k0 + 4fh + kofs, kofs = 32kb + (r&3) + 8(r>>2); visible iff kofs <= klim
-      int klim = p.S - 1 - k0 - 4 * fh;
-      if (causal) klim = min(klim, qi + p.start_pos - k0 - 4 * fh);
-      const unsigned long long lm = range_bits64(0, klim + 1) & (vis >> (4 * fh));
-      const unsigned lmw[2] = {(unsigned)lm, (unsigned)(lm >> 32)};
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float pr = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, neg_lse));
-          pr = ((lmw[kb] >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pr : 0.f;
-          ds[kb][r >> 3][r & 7] = (bf16)(pr * dp[kb][r]);
-        }
-    } else {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, neg_lse));
-          ds[kb][r >> 3][r & 7] = (bf16)(pr * dp[kb][r]);
-        }
+      for (int r = 0; r < 16; ++r) {
+        float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c, neg_lse));
+        pr = ((lmw[kb] >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pr : 0.f;
+        ds[kb][r >> 3][r & 7] = (bf16)(pr * dp[r]);
+      }
     }
     // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]; K^T fragments by asm transposing reads, one ahead.
     // Base addresses per (d block, row / row+8); key block and k-step go into the offset field.
