@@ -303,10 +303,21 @@ constexpr int vy_cmax(int a, int b) { return a > b ? a : b; }
 // ---- shared epilogue of the bf16 kernels ------------------------------------------------------
 // PASSES > 1: the staged tile does not fit next to a second resident workgroup's LDS, so it goes out in
 // PASSES row bands of BM / PASSES rows (each band is owned by whole wave rows: WGM % PASSES == 0).
-template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD, int PASSES = 1, bool PF_OK = true>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM / (32 * WGM)], char* smem,
+// the wave's accumulators: 32 x 32 blocks of mfma_f32_32x32x16 (f32x16 each), or -- MF16 -- 16 x 16 blocks of
+// mfma_f32_16x16x32 (f32x4 each: a lane owns output row lane & 15 of the block and the 4 consecutive columns
+// 4 * (lane >> 4) .. + 3).  Either way a lane holds QUADS of 4 consecutive columns of one row, which is all the
+// staged epilogue needs to know.
+template <int BM, int BN, int WGM, int WGN, bool MF16> struct AccTile {
+  typedef f32x16 T32[BN / (32 * WGN)][BM / (32 * WGM)];
+  typedef f32x4 T16[BN / (16 * WGN)][BM / (16 * WGM)];
+  typedef std::conditional_t<MF16, T16, T32> type;
+};
+
+template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD, int PASSES = 1, bool PF_OK = true, bool MF16 = false>
+__device__ __forceinline__ void gemm_epilogue(typename AccTile<BM, BN, WGM, WGN, MF16>::type& acc, char* smem,
                                               int m0, int n0, int M, int N, const EpiPlain<bf16>& ep,
                                               const EpiQkv<bf16>& eq) {
+  static_assert(!MF16 || PASSES == 1, "the 16 x 16 accumulator layout is staged in one pass");
   constexpr int NW = WGM * WGN, NT = 64 * NW;
   constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
   constexpr int EROW = BN * 2 + 16;
@@ -343,6 +354,42 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) bq[e] = (biasp && n + e < N) ? (float)biasp[n + e] : 0.f;
+    }
+  };
+  // phase 1 of a pass: every quad of the wave's sub-tile that lies in the pass's row band, + bias, -> LDS
+  auto stage_all = [&](int pass) {
+    if constexpr (!MF16) {
+      if (PASSES == 1 || pass == my_pass) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            float bq[4];
+            bias_quad(n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, bq);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] + bq[e];
+              stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
+            }
+          }
+      }
+    } else {
+      constexpr int TM16 = BM / (16 * WGM), TN16 = BN / (16 * WGN);
+      const int r16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < TN16; ++i) {
+        float bq[4];
+        bias_quad(n0 + wn * 16 * TN16 + 16 * i + 4 * kq, bq);
+#pragma unroll
+        for (int j = 0; j < TM16; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] + bq[e];
+          stage_quad(wm * 16 * TM16 + 16 * j + r16, wn * 16 * TN16 + 16 * i + 4 * kq, v);
+        }
+      }
     }
   };
 
@@ -478,22 +525,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
     const bool dual = !GRAD && ep.pre != nullptr;   // (the GRAD path never sets ep.pre)
 #pragma unroll 1
     for (int pass = 0; pass < PASSES; ++pass) {
-      if (PASSES == 1 || pass == my_pass) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            float bq[4];
-            bias_quad(n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, bq);
-#pragma unroll
-            for (int j = 0; j < TM; ++j) {
-              float v[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] + bq[e];
-              stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
-            }
-          }
-      }
+      stage_all(pass);
       __syncthreads();
       flush_plain(ep.y, true, dual, pass);
       if (pass + 1 < PASSES) __syncthreads();
@@ -536,22 +568,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BN / (32 * WGN)][BM 
         }
       }
     }
-    if (PASSES == 1 || pass == my_pass) {
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        float bq[4];
-        bias_quad(n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, bq);
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rg + e] + bq[e];
-          stage_quad(wm * 32 * TM + j * 32 + fr, wn * 32 * TN + i * 32 + 8 * rg + 4 * fh, v);
-        }
-      }
-    }
+    stage_all(pass);
     if constexpr (TAB) {
       if (use_tab) {
 #pragma unroll
@@ -927,6 +944,144 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
   gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
   VY_CLK_MARK(2)
   VY_CLK_END()
+}
+
+// ------------------------------------------------------------------------------------------
+// The same kernel on mfma_f32_16x16x32_bf16: 4 x 6 blocks of 16 x 16 per wave (96 accumulator registers as before),
+// 24 MFMAs per 32-deep k-step, two k-steps per stage.  Same LDS image, same swizzle (conflict-free for this
+// fragment shape too: rows lane & 15, chunk 4 ks + (lane >> 4)), same ring, same epilogue (a lane still owns quads of 4
+// consecutive columns of one row).  Why: the chip holds a higher clock on this MFMA shape and the loop needs fewer
+// cycles per stage (tools/probe/gemm_loop_probe.hip, QUICK=1: 2250-2270 against 2380; MI355X_MICROARCH.md, DVFS
+// give-back item 7).  Per output element the k order is unchanged (one chain over k in steps of 32 instead of 16),
+// so results can differ from the 32 x 32 x 16 kernel only in the rounding of the fp32 chain.
+// ------------------------------------------------------------------------------------------
+template <int BN, int EPI, int ACT, bool GRAD>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_x3m16_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq, int knob) {
+  constexpr int BM = 256, WGM = 4, WGN = 2, NW = 8;
+  constexpr int TM = BM / (16 * WGM), TN = BN / (16 * WGN);   // 4, 6
+  constexpr int PX = BM / 8, PW = BN / 8;
+  constexpr int GX = PX / NW, GW = PW / NW;
+  static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
+  constexpr int XT = BM * ROWB, WT = BN * ROWB;
+  constexpr int WOFF = 3 * XT;
+  constexpr int LDS_BYTES = vy_cmax(3 * XT + 2 * WT, epi_lds_bytes(BM, BN, EPI, 1));
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  int tile_m, tile_n;
+  tile_of(blockIdx.x, gridDim.x, tiles_n, !(knob & 32), tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lrow = lane >> 3, slot = lane & 7;
+  const bf16* xsrc[GX]; int xk[GX];
+  const bf16* wsrc[GW]; int wk[GW];
+#pragma unroll
+  for (int t = 0; t < GX; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gm = m0 + R; gm = gm < M ? gm : M - 1;
+    xsrc[t] = X + (int64_t)gm * ldx + g * 8;
+    xk[t] = g * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gn = n0 + R; gn = gn < N ? gn : N - 1;
+    wsrc[t] = W + (int64_t)gn * ldw + g * 8;
+    wk[t] = g * 8;
+  }
+  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
+  const bool ktail = (K % BK) != 0;
+  const int KT = (K + BK - 1) / BK;
+  auto stage_x = [&](int kt) {
+    char* xb = smem + (kt % 3) * XT;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int t = 0; t < GX; ++t) {
+      const bf16* s = xsrc[t] + k0;
+      if (ktail && k0 + xk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_w = [&](int kt) {
+    char* wb = smem + WOFF + (kt & 1) * WT;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int t = 0; t < GW; ++t) {
+      const bf16* s = wsrc[t] + k0;
+      if (ktail && k0 + wk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, kq = lane >> 4, fsw = (r16 >> 1) & 7;
+  unsigned xa[2], wa[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int coff = (((ks * 4 + kq) ^ fsw) << 4);
+    xa[ks] = vy_lds_addr(smem) + (wm * 16 * TM + r16) * ROWB + coff;
+    wa[ks] = vy_lds_addr(smem) + WOFF + (wn * 16 * TN + r16) * ROWB + coff;
+  }
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; w_[i] = vy_lds_read128_off<i * 16 * ROWB>(wbase); });
+    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; x_[j] = vy_lds_read128_off<j * 16 * ROWB>(xbase); });
+  };
+  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) vy_tie(w_[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) vy_tie(x_[j]);
+  };
+  auto mma = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_[i], x_[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  stage_x(0);
+  stage_w(0);
+  if (KT > 1) stage_x(1);
+  if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(wa[0], xa[0], wf[0], xf[0]);
+  int xbuf = 0;   // kt % 3
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) stage_w(kt + 1);
+    if (kt + 2 < KT) stage_x(kt + 2);
+    const unsigned xo = xbuf * XT, wo = (kt & 1) * WT;
+    read_frags(wa[1] + wo, xa[1] + xo, wf[1], xf[1]);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+    tie_frags(wf[0], xf[0]);
+    mma(wf[0], xf[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tie_frags(wf[1], xf[1]);
+    mma(wf[1], xf[1]);
+    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    xbuf = xbuf == 2 ? 0 : xbuf + 1;
+    if (kt + 1 < KT) read_frags(wa[0] + (WT - wo), xa[0] + xbuf * XT, wf[0], xf[0]);
+  }
+  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD, 1, true, true>(acc, smem, m0, n0, M, N, ep, eq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2297,7 +2452,12 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     if ((var == 20 || var == 21) && !(pp_ok && N >= pp_min_n)) var = 14;
     // persistent kernel with the epilogue pipelined into the next tile's k-loop: whole tiles, K a multiple of 64
     // and >= 12 stages, plain epilogue without residual / dropout, and at least two tiles per CU
-    static const int pipe_env = [] { const char* e = getenv("VY_GEMM_PIPE"); return e ? atoi(e) : 1; }();
+    // (the persistent pipelined kernel: 5-6 % ahead of the 32 x 32 x 16 one-shot kernel on plain N = 2304 launches on
+    // some boxes, behind it on others, and behind the 16 x 16 x 32 one-shot kernel everywhere measured: opt-in)
+    static const int pipe_env = [] { const char* e = getenv("VY_GEMM_PIPE"); return e ? atoi(e) : 0; }();
+    // 16 x 16 x 32 MFMAs in the X-ring kernel: bit-identical outputs, 8-12 % faster on the K >= 2304 launches and the
+    // dgrads, 3-8 % on K = 768 (tools/exp_gemm.py -1 40, tools/bench_dgrad.py -1 40); VY_GEMM_M16=0: the 32 x 32 x 16 kernel
+    static const int m16_env = [] { const char* e = getenv("VY_GEMM_M16"); return e ? atoi(e) : 1; }();
     int pipe_on = pipe_env;
     if (var == 31) { var = 14; pipe_on = 0; }   // the default selection without the pipelined kernel (A/B runs, tests)
     if constexpr (EPI == 0 && !GRAD) {
@@ -2338,6 +2498,9 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     } else if (var == 11) {  // 4 waves, 128 x 96 per wave
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
+    } else if (var == 40 || (m16_env && (var == 14 && !wide))) {  // the x3 kernel on 16 x 16 x 32 MFMAs
+      hipLaunchKernelGGL((gemm_nt_bf16_x3m16_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     } else if (var == 13 || (var == 14 && !wide) || (var == 15 && !wide)) {  // X in a 3-deep ring, W in two buffers
       hipLaunchKernelGGL((gemm_nt_bf16_x3_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
