@@ -1085,6 +1085,129 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3m16_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tiles, two whole stages (128 KiB), on mfma_f32_16x16x32_bf16: the wide launches (FFN1, the dgrad of
+// FFN2, the vocabulary projection), where the tile's fewer operand bytes per FLOP matter more than a third X stage.
+// 4 x 8 blocks of 16 x 16 per wave (128 accumulator registers), 32 MFMAs per k-step, fragments double-buffered.
+// ------------------------------------------------------------------------------------------
+template <int EPI, int ACT, bool GRAD>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_w256m16_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq, int knob) {
+  constexpr int BM = 256, BN = 256, WGM = 4, WGN = 2, NW = 8;
+  constexpr int TM = BM / (16 * WGM), TN = BN / (16 * WGN);   // 4, 8
+  constexpr int PX = BM / 8, PW = BN / 8;
+  constexpr int GX = PX / NW, GW = PW / NW;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int LDS_BYTES = vy_cmax(2 * STAGE, epi_lds_bytes(BM, BN, EPI, 1));
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  int tile_m, tile_n;
+  tile_of(blockIdx.x, gridDim.x, tiles_n, !(knob & 32), tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int lrow = lane >> 3, slot = lane & 7;
+  const bf16* xsrc[GX]; int xk[GX];
+  const bf16* wsrc[GW]; int wk[GW];
+#pragma unroll
+  for (int t = 0; t < GX; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gm = m0 + R; gm = gm < M ? gm : M - 1;
+    xsrc[t] = X + (int64_t)gm * ldx + g * 8;
+    xk[t] = g * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gn = n0 + R; gn = gn < N ? gn : N - 1;
+    wsrc[t] = W + (int64_t)gn * ldw + g * 8;
+    wk[t] = g * 8;
+  }
+  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
+  const bool ktail = (K % BK) != 0;
+  const int KT = (K + BK - 1) / BK;
+  auto stage = [&](int kt, int buf) {
+    char* xb = smem + buf * STAGE;
+    char* wb = xb + BM * ROWB;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int t = 0; t < GX; ++t) {
+      const bf16* s = xsrc[t] + k0;
+      if (ktail && k0 + xk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < GW; ++t) {
+      const bf16* s = wsrc[t] + k0;
+      if (ktail && k0 + wk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, kq = lane >> 4, fsw = (r16 >> 1) & 7;
+  unsigned xa[2], wa[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int coff = (((ks * 4 + kq) ^ fsw) << 4);
+    xa[ks] = vy_lds_addr(smem) + (wm * 16 * TM + r16) * ROWB + coff;
+    wa[ks] = vy_lds_addr(smem) + BM * ROWB + (wn * 16 * TN + r16) * ROWB + coff;
+  }
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; w_[i] = vy_lds_read128_off<i * 16 * ROWB>(wbase); });
+    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; x_[j] = vy_lds_read128_off<j * 16 * ROWB>(xbase); });
+  };
+  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) vy_tie(w_[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) vy_tie(x_[j]);
+  };
+  auto mma = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_[i], x_[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(wa[0], xa[0], wf[0], xf[0]);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+    const unsigned boff = cur * STAGE;
+    read_frags(wa[1] + boff, xa[1] + boff, wf[1], xf[1]);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+    tie_frags(wf[0], xf[0]);
+    mma(wf[0], xf[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tie_frags(wf[1], xf[1]);
+    mma(wf[1], xf[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < KT) read_frags(wa[0] + (STAGE - boff), xa[0] + (STAGE - boff), wf[0], xf[0]);
+  }
+  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD, 1, true, true>(acc, smem, m0, n0, M, N, ep, eq);
+}
+
+// ------------------------------------------------------------------------------------------
 // PERSISTENT 256 x 192 kernel with the epilogue of tile t software-pipelined into the k-loop of tile t+1.
 //
 // Measured on the forward launches of a layer (tools/gemm_diag2.py, workgroup 0, K = 768): the k-loop is 34 k
@@ -2499,6 +2622,10 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     } else if (var == 11) {  // 4 waves, 128 x 96 per wave
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
+    } else if (var == 41 || (m16_env && var == 14 && wide)) {  // 256 x 256 tiles on 16 x 16 x 32 MFMAs (FFN1 -8 %, vocabulary projection -7.5 %)
+      const int tn2 = (int)vy_cdiv(N, 256);
+      hipLaunchKernelGGL((gemm_nt_bf16_w256m16_kernel<EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
     } else if (var == 40 || (m16_env && (var == 14 && !wide))) {  // the x3 kernel on 16 x 16 x 32 MFMAs
       hipLaunchKernelGGL((gemm_nt_bf16_x3m16_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
