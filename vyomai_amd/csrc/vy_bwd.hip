@@ -49,7 +49,13 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
 // NS == 0 selects the asymmetric ring: the dY tile three deep, the X tile two deep (3*ATILE + 2*BTILE =
 // 80 KiB at 128 x 128 x 64: still two workgroups per CU) -- the dY loads of stage s+2 stay in flight
 // across the barrier that ends stage s, as X does in gemm_nt_bf16_x3_kernel.
-template <int BN, int BKW, int MS, int NS>
+// MF16: mfma_f32_16x16x32_bf16 instead of 32x32x16 (as in the forward / dgrad GEMMs: fewer cycles per stage and a higher
+// clock, vy_gemm.hip): 4 x WKT/16 blocks of 16 x 16 per wave, 32 rows of m per MFMA.  The transposing reads of a 16-lane
+// group take the 4 rows 4 (lane >> 4) + q (and + 16), so the two groups of a 32-lane half read DIFFERENT rows of the same
+// columns: the source-side swizzle gets a second bit ((row >> 2) & 1) << 5 that puts them in the two 32-byte halves of a
+// 64-byte slot (conflict-free).  The atomic epilogue exchanges lane halves of two neighbouring k blocks
+// (v_permlane32_swap) so that a wave instruction is again two 128-byte row segments.
+template <int BN, int BKW, int MS, int NS, bool MF16 = false>
 __device__ __forceinline__ void wgrad_tn_bf16_body(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
     float* __restrict__ dW, int64_t lddw, float* __restrict__ db, const float* __restrict__ alpha_dev,
@@ -82,14 +88,14 @@ __device__ __forceinline__ void wgrad_tn_bf16_body(
     const int P = (wave * PA + t) * 1024 + lane * 16;
     const int row = P / AROW, off = P % AROW;
     a_row[t] = row;
-    a_off[t] = (off ^ ((row & 3) << 6)) >> 1;
+    a_off[t] = (off ^ (((row & 3) << 6) | (MF16 ? ((row >> 2) & 1) << 5 : 0))) >> 1;
   }
 #pragma unroll
   for (int t = 0; t < PB; ++t) {
     const int P = (wave * PB + t) * 1024 + lane * 16;
     const int row = P / BROW, off = P % BROW;
     b_row[t] = row;
-    b_off[t] = (off ^ ((row & 3) << 6)) >> 1;
+    b_off[t] = (off ^ (((row & 3) << 6) | (MF16 ? ((row >> 2) & 1) << 5 : 0))) >> 1;
   }
   const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
   // Per-piece source pointers are advanced by MS rows per stage (one 64-bit add each) instead of being
@@ -136,6 +142,125 @@ __device__ __forceinline__ void wgrad_tn_bf16_body(
     stage_b(s, smem + buf * STAGE + ATILE);
   };
 
+  if constexpr (MF16) {
+    static_assert(MS % 32 == 0 && !(NS == 0), "16x16x32: stages of 32-row k-steps, symmetric ring");
+    constexpr int TI = 4, TJ16 = WKT / 16, KS16 = MS / 32, JH = TJ16 / 2;
+    f32x4 acc[TI][TJ16];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_db = db != nullptr && tile_k == 0 && wk == 0;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+    float sdb[TI] = {0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int q_ = r16 >> 2, p_ = r16 & 3;
+    const int sw16 = (q_ << 6) | ((kq & 1) << 5);
+    unsigned a_lds[TI], b_lds[TJ16];   // stage 0, k-step 0, first read (rows 4 kq + q_)
+#pragma unroll
+    for (int i = 0; i < TI; ++i) a_lds[i] = vy_lds_addr(smem) + (4 * kq + q_) * AROW + ((2 * (wn * 64 + 16 * i + 4 * p_)) ^ sw16);
+#pragma unroll
+    for (int j = 0; j < TJ16; ++j) b_lds[j] = vy_lds_addr(smem) + (4 * kq + q_) * BROW + ((2 * (wk * WKT + 16 * j + 4 * p_)) ^ sw16);
+#pragma unroll
+    for (int s_ = 0; s_ < NS - 1; ++s_)
+      if (s_ < nst) stage(s_, s_);
+    for (int s = 0; s < nst; ++s) {
+      const int cur = s % NS;
+      const int younger = min(NS - 2, nst - 1 - s);
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PA + PB)) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (s + NS - 1 < nst) stage(s + NS - 1, (s + NS - 1) % NS);
+      unsigned a_base[TI], b_base[TJ16];
+#pragma unroll
+      for (int i = 0; i < TI; ++i) a_base[i] = a_lds[i] + cur * STAGE;
+#pragma unroll
+      for (int j = 0; j < TJ16; ++j) b_base[j] = b_lds[j] + cur * STAGE;
+      // per k-step: the dY fragments and the first half of the X fragments, the second half requested before the
+      // first half's MFMAs (counted lgkmcnt: two reads per fragment)
+      vy_static_for<KS16>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        bf16x8 af[TI], bfr[TJ16];
+        vy_static_for<TI>([&](auto i_c) {
+          constexpr int i = decltype(i_c)::value;
+          af[i] = vy_lds_tr16_pair_off<32 * ks * AROW, (32 * ks + 16) * AROW>(a_base[i]);
+        });
+        vy_static_for<JH>([&](auto j_c) {
+          constexpr int j = decltype(j_c)::value;
+          bfr[j] = vy_lds_tr16_pair_off<ATILE + 32 * ks * BROW, ATILE + (32 * ks + 16) * BROW>(b_base[j]);
+        });
+        vy_static_for<JH>([&](auto j_c) {
+          constexpr int j = JH + decltype(j_c)::value;
+          bfr[j] = vy_lds_tr16_pair_off<ATILE + 32 * ks * BROW, ATILE + (32 * ks + 16) * BROW>(b_base[j]);
+        });
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * JH) : "memory");
+#pragma unroll
+        for (int i = 0; i < TI; ++i) vy_tie(af[i]);
+#pragma unroll
+        for (int j = 0; j < JH; ++j) vy_tie(bfr[j]);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < JH; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = JH; j < TJ16; ++j) vy_tie(bfr[j]);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = JH; j < TJ16; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (do_db) {
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            union { bf16x8 v; bf16x2_t h[4]; } u_;
+            u_.v = af[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sdb[i] = __builtin_amdgcn_fdot2_f32_bf16(u_.h[e], ones2, sdb[i], false);
+          }
+        }
+      });
+    }
+    if (diag == 1) {  // timing-only: no atomic epilogue (results wrong)
+      if (acc[0][0][0] == 12345.678f) dW[0] = 1.f;
+      return;
+    }
+    const float alpha = alpha_dev ? *alpha_dev : 1.0f;
+    if (do_db) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        float t_ = sdb[i];
+        t_ += __shfl_xor(t_, 16, 64);
+        t_ += __shfl_xor(t_, 32, 64);
+        const int n = n0 + wn * 64 + 16 * i + r16;
+        if (kq == 0 && n < N) atomicAdd(db + n, t_ * alpha);
+      }
+    }
+    // D[n][k] of block (i, j): lane = k index (lane & 15), register r = n row 4 kq + r.  Blocks j and j + 1 trade lane
+    // halves so that one wave instruction adds rows {r, 4 + r} (then {8 + r, 12 + r}) x 32 consecutive k
+    const bool hi = lane >= 32;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int jp = 0; jp < JH; ++jp) {
+        const int k = k0 + wk * WKT + 16 * (2 * jp + (hi ? 1 : 0)) + r16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned x = __builtin_bit_cast(unsigned, acc[i][2 * jp][r] * alpha);
+          const unsigned y = __builtin_bit_cast(unsigned, acc[i][2 * jp + 1][r] * alpha);
+          auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+          const int nlo = n0 + wn * 64 + 16 * i + 4 * (kq & 1) + r;
+          if (k < K) {
+            if (nlo < N) atomicAdd(dW + (int64_t)nlo * lddw + k, __builtin_bit_cast(float, (unsigned)sw[0]));
+            if (nlo + 8 < N) atomicAdd(dW + (int64_t)(nlo + 8) * lddw + k, __builtin_bit_cast(float, (unsigned)sw[1]));
+          }
+        }
+      }
+  } else {
   f32x16 acc[2][TJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -272,14 +397,15 @@ __device__ __forceinline__ void wgrad_tn_bf16_body(
         if (n < N) atomicAdd(dW + (int64_t)n * lddw + k, acc[i][j][r] * alpha);
       }
     }
+  }
 }
 
-template <int BN, int BKW, int MS, int NS>
+template <int BN, int BKW, int MS, int NS, bool MF16 = false>
 __global__ __launch_bounds__(BN * 2, BN == 128 ? 2 : 1) void wgrad_tn_bf16_kernel(
     const bf16* __restrict__ dY, int64_t lddy, const bf16* __restrict__ X, int64_t ldx,
     float* __restrict__ dW, int64_t lddw, float* __restrict__ db, const float* __restrict__ alpha_dev,
     int M, int N, int K, int tiles_k, int tiles_nk, int m_chunk, int diag) {
-  wgrad_tn_bf16_body<BN, BKW, MS, NS>(dY, lddy, X, ldx, dW, lddw, db, alpha_dev, M, N, K, tiles_k, tiles_nk, m_chunk,
+  wgrad_tn_bf16_body<BN, BKW, MS, NS, MF16>(dY, lddy, X, ldx, dW, lddw, db, alpha_dev, M, N, K, tiles_k, tiles_nk, m_chunk,
                                       diag, xcd_remap(blockIdx.x, gridDim.x));
 }
 
@@ -293,7 +419,7 @@ struct WgradItem {
 };
 struct WgradGroup { WgradItem g[8]; int n; };
 
-template <int BN, int BKW, int MS, int NS>
+template <int BN, int BKW, int MS, int NS, bool MF16 = false>
 __global__ __launch_bounds__(BN * 2, 1) void wgrad_tn_bf16_grouped_kernel(WgradGroup grp, int diag) {
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   int d = 0;
@@ -305,7 +431,7 @@ __global__ __launch_bounds__(BN * 2, 1) void wgrad_tn_bf16_grouped_kernel(WgradG
 #pragma unroll
   for (int i = 1; i < 8; ++i)
     if (d == i) it = grp.g[i];
-  wgrad_tn_bf16_body<BN, BKW, MS, NS>(it.dY, it.lddy, it.X, it.ldx, it.dW, it.lddw, it.db, nullptr, it.M, it.N, it.K,
+  wgrad_tn_bf16_body<BN, BKW, MS, NS, MF16>(it.dY, it.lddy, it.X, it.ldx, it.dW, it.lddw, it.db, nullptr, it.M, it.N, it.K,
                                       it.tiles_k, it.tiles_nk, it.m_chunk, diag, id - it.item0);
 }
 
@@ -862,15 +988,24 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
   hipLaunchKernelGGL((wgrad_tn_bf16_kernel<BN_, BK_, MS_, NS_>), dim3((unsigned)(tiles * splits)), dim3(BN_ * 2), 0, \
                      st, (const bf16*)dy, lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, \
                      (int)K, tiles_k, tiles, (int)m_chunk, diag)
+#define WG_GO16(BN_, BK_, MS_, NS_)                                                                        \
+  hipLaunchKernelGGL((wgrad_tn_bf16_kernel<BN_, BK_, MS_, NS_, true>), dim3((unsigned)(tiles * splits)), dim3(BN_ * 2), 0, \
+                     st, (const bf16*)dy, lddy, (const bf16*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, \
+                     (int)K, tiles_k, tiles, (int)m_chunk, diag)
+  // 16 x 16 x 32 MFMAs: 3 % faster on the 256 x 256 tiles (vocabulary projection 1.62 -> 1.57 ms, +0.25 % on the training
+  // step), 2-8 % SLOWER on the 128 x 128 tiles (these kernels are bound by the transposing LDS reads and the atomic
+  // epilogue, not by the matrix pipe): 1 = the wide tiles only (default), 2 = everywhere, 0 = off
+  static const int w16 = [] { const char* e = getenv("VY_WGRAD_M16"); return e ? atoi(e) : 1; }();
   if (var == 1) { if (ns == 3) WG_GO(256, 128, 64, 3); else WG_GO(256, 128, 64, 2); }
   else if (var == 2) WG_GO(128, 256, 32, 2);
   else if (var == 4) WG_GO(128, 256, 32, 3);
   else if (var == 5) WG_GO(128, 128, 32, 2);   // 32 KiB of LDS: three workgroups per CU
   else if (var == 6) WG_GO(128, 128, 64, 0);   // dY three deep, X two deep: 80 KiB, two workgroups per CU
   else if (var == 7) WG_GO(256, 256, 32, 3);   // 7.8 LDS-DMA bytes per kFLOP, 96 KiB
-  else if (var == 8) WG_GO(256, 256, 32, 4);   // ... 128 KiB
-  else { if (ns == 3) WG_GO(128, 128, 64, 3); else WG_GO(128, 128, 64, 2); }
+  else if (var == 8) { if (w16) WG_GO16(256, 256, 32, 4); else WG_GO(256, 256, 32, 4); }   // ... 128 KiB
+  else { if (ns == 3) WG_GO(128, 128, 64, 3); else if (w16 >= 2) WG_GO16(128, 128, 64, 2); else WG_GO(128, 128, 64, 2); }
 #undef WG_GO
+#undef WG_GO16
   VY_CHECK_LAUNCH(who);
   return VY_OK;
 }
@@ -908,8 +1043,16 @@ extern "C" int vy_linear_wgrad_grouped(const vy_wgrad_desc* descs, int32_t n, in
     items += tiles * splits;
   }
   for (int i = n; i < 8; ++i) grp.g[i] = grp.g[0];
-  hipLaunchKernelGGL((wgrad_tn_bf16_grouped_kernel<256, 256, 32, 4>), dim3((unsigned)items), dim3(512), 0, (hipStream_t)stream,
-                     grp, diag);
+  // 16 x 16 x 32 MFMAs: 3 % faster on the 256 x 256 tiles (vocabulary projection 1.62 -> 1.57 ms, +0.25 % on the training
+  // step), 2-8 % SLOWER on the 128 x 128 tiles (these kernels are bound by the transposing LDS reads and the atomic
+  // epilogue, not by the matrix pipe): 1 = the wide tiles only (default), 2 = everywhere, 0 = off
+  static const int w16 = [] { const char* e = getenv("VY_WGRAD_M16"); return e ? atoi(e) : 1; }();
+  if (w16)
+    hipLaunchKernelGGL((wgrad_tn_bf16_grouped_kernel<256, 256, 32, 4, true>), dim3((unsigned)items), dim3(512), 0,
+                       (hipStream_t)stream, grp, diag);
+  else
+    hipLaunchKernelGGL((wgrad_tn_bf16_grouped_kernel<256, 256, 32, 4>), dim3((unsigned)items), dim3(512), 0, (hipStream_t)stream,
+                       grp, diag);
   VY_CHECK_LAUNCH(who);
   return VY_OK;
 }
