@@ -255,7 +255,7 @@ def test_grouped_weight_gradients_match_ungrouped():
         real_ready = tr.reducer.mark_ready
 
         def spy(p):
-            if any(p is w or p is b for _, _, w, b in AT._wgrad_group.items):
+            if any(p is q for *_, members in AT._wgrad_group.items for q in members):
                 early.append(p)
             real_ready(p)
 

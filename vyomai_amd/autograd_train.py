@@ -133,13 +133,17 @@ class _WgradGroup:
         return dy.numel() // N >= _GROUP_MIN_ROWS and N < 8192 and N * K >= 512 * 512 and K % 8 == 0
 
     def add(self, dy, x, w, b) -> None:
-        self.items.append((dy, x, w, b))
+        self.add_tensors(dy, x, w.grad, None if b is None else b.grad, [p for p in (w, b) if p is not None])
+
+    def add_tensors(self, dy, x, dw, db, members) -> None:
+        """dw / db: the fp32 gradient tensors the launch accumulates into (views of the arena); members: the
+        parameters to report ready once it has been enqueued (a packed projection has several)."""
+        self.items.append((dy, x, dw, db, members))
         # autograd's own post-accumulate hook fires for these parameters as soon as this backward function
         # returns -- the reducer must not take that for "gradient written" (training.BucketReducer._hook)
-        w._vy_deferred = True
-        if b is not None:
-            b._vy_deferred = True
-        self.tiles += -(-w.shape[0] // 256) * -(-w.shape[1] // 256)
+        for p in members:
+            p._vy_deferred = True
+        self.tiles += -(-dw.shape[0] // 256) * -(-dw.shape[1] // 256)
         if not self.armed:
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
             self.armed = True
@@ -150,28 +154,27 @@ class _WgradGroup:
         items, self.items, self.tiles = self.items, [], 0
         if not items:
             return
-        ops.linear_wgrad_grouped([(dy, x, w.grad, None if b is None else b.grad) for dy, x, w, b in items])
-        for _, _, w, b in items:
-            w._vy_deferred = False
-            if b is not None:
-                b._vy_deferred = False
-            _notify(w, b)
+        ops.linear_wgrad_grouped([(dy, x, dw, db) for dy, x, dw, db, _ in items])
+        for *_, members in items:
+            for p in members:
+                p._vy_deferred = False
+            _notify(*members)
 
     def _end_of_backward(self) -> None:
         self.armed = False
         self.flush()
 
     def discard(self) -> None:
-        for _, _, w, b in self.items:
-            w._vy_deferred = False
-            if b is not None:
-                b._vy_deferred = False
+        for *_, members in self.items:
+            for p in members:
+                p._vy_deferred = False
         self.items, self.tiles, self.armed = [], 0, False
 
 
 _GROUP_WGRADS = os.environ.get("VY_WGRAD_GROUP", "1") != "0"
 _DEFER_RESIDUALS = os.environ.get("VY_DEFER_RESIDUALS", "1") != "0"
 _GROUP_MIN_ROWS = int(os.environ.get("VY_WGRAD_GROUP_ROWS", "2048"))   # measured on configs[3] (2112 decoder rows): -6 %
+_GROUP_QKV = os.environ.get("VY_WGRAD_GROUP_QKV", "1") != "0"              # the packed QKV gradient joins the group
 _wgrad_group = _WgradGroup()
 
 
@@ -490,8 +493,14 @@ def _packed_wgrad(mod, dy, x, w, b, params):
             db = torch.as_strided(db0, (N,), (1,))
             ok = ok and all(p.grad.data_ptr() == db0.data_ptr() + off * 4 for p, off in zip(bs, _offsets(bs)))
         if ok:
-            ops.linear_wgrad(dy, x, dw, db, accumulate=True)
-            _notify(*members)
+            dy2 = dy.view(-1, dy.shape[-1])
+            if _GROUP_WGRADS and _GROUP_QKV and dy2.shape[0] >= _GROUP_MIN_ROWS and N * dw.shape[1] >= 512 * 512 and dw.shape[1] % 8 == 0:
+                # with the layer's other weight gradients in one grouped launch (27 of its 108 tiles: on its own
+                # this launch ran at 670 TFLOP/s, the group at 850)
+                _wgrad_group.add_tensors(dy2, x.view(-1, x.shape[-1]), dw, db, list(members))
+            else:
+                ops.linear_wgrad(dy, x, dw, db, accumulate=True)
+                _notify(*members)
             return [None] * len(params)
     N, K = w.shape
     dw = torch.empty((N, K), dtype=torch.float32, device=w.device)
