@@ -140,7 +140,7 @@ def roofline_probe(cfg, B, L, dev):
         except (OSError, KeyError, ValueError):
             continue
     return {
-        "bound": "mfma", "kernel": "gemm_nt_bf16_x3m16_kernel / gemm_nt_bf16_w256m16_kernel (4 launches of one layer: qkv+rope, out+res, "
+        "bound": "mfma", "kernel": "gemm_nt_bf16_x3m16_kernel / gemm_nt_bf16_m16_kernel<256,256> (4 launches of one layer: qkv+rope, out+res, "
                                    "ffn1+gelu, ffn2+res)",
         "achieved": round(f_gemm / t_gemm * 1e-6, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(f_gemm / t_gemm * 1e-6 / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

@@ -1085,18 +1085,20 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_x3m16_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// 256 x 256 x 64 tiles, two whole stages (128 KiB), on mfma_f32_16x16x32_bf16: the wide launches (FFN1, the dgrad of
-// FFN2, the vocabulary projection), where the tile's fewer operand bytes per FLOP matter more than a third X stage.
-// 4 x 8 blocks of 16 x 16 per wave (128 accumulator registers), 32 MFMAs per k-step, fragments double-buffered.
+// BM x BN x 64 tiles, two whole stages, on mfma_f32_16x16x32_bf16.  256 x 256 (8 waves, 128 KiB): the wide launches (FFN1,
+// the dgrad of FFN2, the vocabulary projection), where the tile's fewer operand bytes per FLOP matter more than a third X
+// stage; 4 x 8 blocks of 16 x 16 per wave (128 accumulator registers), 32 MFMAs per k-step, fragments double-buffered.
+// 128 x 128 (4 waves, 64 KiB, two workgroups per CU): mid-size M.
 // ------------------------------------------------------------------------------------------
-template <int EPI, int ACT, bool GRAD>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_w256m16_kernel(
+template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_m16_kernel(
     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
     int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq, int knob) {
-  constexpr int BM = 256, BN = 256, WGM = 4, WGN = 2, NW = 8;
-  constexpr int TM = BM / (16 * WGM), TN = BN / (16 * WGN);   // 4, 8
+  constexpr int NW = WGM * WGN;
+  constexpr int TM = BM / (16 * WGM), TN = BN / (16 * WGN);   // 256 x 256, 4 x 2 waves: 4, 8;  128 x 128, 2 x 2 waves: 4, 4
   constexpr int PX = BM / 8, PW = BN / 8;
   constexpr int GX = PX / NW, GW = PW / NW;
+  static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int LDS_BYTES = vy_cmax(2 * STAGE, epi_lds_bytes(BM, BN, EPI, 1));
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
@@ -2555,8 +2557,13 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     // mid-size M: also whenever the 256 x 192 grid would leave more than a third of the CUs without a tile
     // (M = 2112 rows of a captioning decoder x N = 768: 36 tiles of 256 x 192, 102 of 128 x 128)
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
-                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
+    static const int mid16 = [] { const char* e = getenv("VY_GEMM_MID16"); return e ? atoi(e) : 1; }();
+    if (mid16)
+      hipLaunchKernelGGL((gemm_nt_bf16_m16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
+    else
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
+                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
   } else {
     const int tn = (int)vy_cdiv(N, 192), tm = (int)vy_cdiv(M, 256);
     // default: 2-stage 64-deep tiles.  256 x 192 divides N in {768, 2304} x M = 16384 into whole
@@ -2624,7 +2631,7 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     } else if (var == 41 || (m16_env && var == 14 && wide)) {  // 256 x 256 tiles on 16 x 16 x 32 MFMAs (FFN1 -8 %, vocabulary projection -7.5 %)
       const int tn2 = (int)vy_cdiv(N, 256);
-      hipLaunchKernelGGL((gemm_nt_bf16_w256m16_kernel<EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
+      hipLaunchKernelGGL((gemm_nt_bf16_m16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
     } else if (var == 40 || (m16_env && (var == 14 && !wide))) {  // the x3 kernel on 16 x 16 x 32 MFMAs
       hipLaunchKernelGGL((gemm_nt_bf16_x3m16_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
