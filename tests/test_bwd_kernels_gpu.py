@@ -109,14 +109,25 @@ BWD_CASES = [
     (3, 12, 12, 197, 197, False, 0, False),
     # odd length, non-causal, key padding (encoder attention under a padding mask)
     (2, 12, 4, 131, 131, False, 0, True),
+    # the other head widths (general kernels: SigLIP 72, 128, Gemma 256, and odd multiples of 8)
+    (2, 4, 2, 130, 130, True, 0, True, 72),
+    (1, 16, 16, 256, 256, False, 0, False, 72),
+    (2, 4, 4, 128, 128, True, 0, False, 128),
+    (2, 4, 2, 200, 200, True, 0, True, 128),
+    (2, 3, 1, 70, 70, False, 0, True, 128),
+    (1, 8, 1, 264, 264, True, 0, False, 256),
+    (2, 2, 2, 97, 97, False, 0, True, 256),
+    (2, 4, 2, 150, 150, True, 0, False, 96),
+    (1, 2, 1, 65, 65, True, 0, False, 160),
+    (1, 2, 2, 64, 64, False, 0, False, 40),
 ]
 
 
 @pytest.mark.parametrize("case", BWD_CASES)
 def test_attention_bwd(case):
     ops = _ops()
-    B, h, hk, L, S, causal, start, use_kp = case
-    dh = 64
+    B, h, hk, L, S, causal, start, use_kp = case[:8]
+    dh = case[8] if len(case) > 8 else 64
     q = rnd(B, h, L, dh, seed=1).to(BF)
     k = rnd(B, hk, S, dh, seed=2).to(BF)
     v = rnd(B, hk, S, dh, seed=3).to(BF)
@@ -168,10 +179,12 @@ def test_adamw_matches_torch():
     check(pb, pt.detach().to(BF), 1e-2, 1e-2, "adamw bf16 shadow")
 
 
-def test_attention_bwd_fused_rope_inverse():
-    """dq/dk with the RoPE backward fused into the epilogues == separate inverse rotation."""
+@pytest.mark.parametrize("dh", [64, 128, 256])
+def test_attention_bwd_fused_rope_inverse(dh):
+    """dq/dk with the RoPE backward inside vy_attn_bwd (fused into the epilogues at dh = 64, rotation launches after
+    the general kernels otherwise) == separate inverse rotation."""
     ops = _ops()
-    B, h, hk, L, dh = 2, 4, 2, 96, 64
+    B, h, hk, L = 2, 4, 2, 96
     q, k, v = rnd(B, h, L, dh, seed=1).to(BF), rnd(B, hk, L, dh, seed=2).to(BF), rnd(B, hk, L, dh, seed=3).to(BF)
     do = rnd(B, L, h * dh, seed=4).to(BF)
     cos, sin = ops.rope_tables(dh, 128, DEV)

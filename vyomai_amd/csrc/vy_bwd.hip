@@ -1057,6 +1057,293 @@ extern "C" int vy_linear_wgrad_grouped(const vy_wgrad_desc* descs, int32_t n, in
   return VY_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Attention backward for the other head widths (any multiple of 8 up to 256; 72 runs as 96): the structure of
+// attn_fwd_gen_kernel (vy_attn.hip) -- register-staged 64-row tiles in LDS, mfma_f32_16x16x32_bf16, a lane owns one
+// row of the "B side" and 4 consecutive rows of the "A side" per 16 x 16 block, products that feed the next MFMA stay
+// in registers with the contraction walked in the order the values sit in, transposed operands by
+// ds_read_b64_tr_b16.  Not tuned like the dh = 64 kernels: it exists so that models with 72 / 128 / 256-wide heads
+// train on the MFMA path at all.
+//   dq kernel   (64 query rows per workgroup, keys swept):  S^T = K Q^T, dP^T = V dO^T (accumulator initialised with
+//               -delta), dS^T = P o (dP - delta), dQ^T += K^T dS^T;  delta = rowsum(dO o O) computed here and left in
+//               delta_ws for the second kernel
+//   dkdv kernel (64 keys per workgroup, query heads of the KV group and query rows swept):  S = Q K^T, dP = dO V^T,
+//               dV^T += dO^T P, dK^T += Q^T dS
+// Rows without a visible key contribute nothing (as in the dh = 64 kernels).
+// ------------------------------------------------------------------------------------------
+template <int DHP>
+struct GenBwd {
+  static constexpr int PITCH = (DHP + 8) * 2, KS = DHP / 32, NDB = DHP / 16, CPRW = DHP / 8, CPT = 64 * CPRW / 256;
+};
+
+__device__ __forceinline__ float gen_groups_sum(float v) {   // over the four 16-lane groups, result in every lane
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
+  const unsigned w = __builtin_bit_cast(unsigned, v);
+  auto s32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __builtin_bit_cast(float, (unsigned)s32[0]) + __builtin_bit_cast(float, (unsigned)s32[1]);
+}
+
+// stage a 64-row tile of a [rows][dh] tensor (row stride `sl` elements) into LDS, zero beyond dh / beyond `nrows`
+template <int DHP>
+__device__ __forceinline__ void gen_stage(char* dst, const bf16* src, int64_t sl, int row0, int nrows, int dh, int tid,
+                                          bf16x8 (&reg)[GenBwd<DHP>::CPT]) {
+  (void)dst;
+  constexpr int CPRW = GenBwd<DHP>::CPRW, CPT = GenBwd<DHP>::CPT;
+  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int cidx = tid + 256 * i;
+    const int row = cidx / CPRW, ch = cidx - row * CPRW;
+    const int r = row0 + row;
+    const bool ok = ch * 8 < dh && r < nrows;
+    reg[i] = ok ? *reinterpret_cast<const bf16x8*>(src + (int64_t)r * sl + ch * 8) : zero8;
+  }
+}
+template <int DHP>
+__device__ __forceinline__ void gen_store(char* dst, int tid, const bf16x8 (&reg)[GenBwd<DHP>::CPT]) {
+  constexpr int CPRW = GenBwd<DHP>::CPRW, CPT = GenBwd<DHP>::CPT, PITCH = GenBwd<DHP>::PITCH;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int cidx = tid + 256 * i;
+    const int row = cidx / CPRW, ch = cidx - row * CPRW;
+    *reinterpret_cast<bf16x8*>(dst + row * PITCH + ch * 16) = reg[i];
+  }
+}
+
+template <int DHP>
+__global__ __launch_bounds__(256) void attn_bwd_gen_dq_kernel(BwdParams p, int dh) {
+  typedef GenBwd<DHP> G;
+  constexpr int PITCH = G::PITCH, KS = G::KS, NDB = G::NDB, CPT = G::CPT;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * PITCH];
+  char* kt = smem;
+  char* vt = smem + 64 * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int head = (int)blockIdx.y % p.h, b = (int)blockIdx.y / p.h;
+  const int kvh = head / (p.h / p.hk);
+  const int q0 = (int)blockIdx.x * 64;
+  const int qi = q0 + wave * 16 + r16;
+  const int qrow = qi < p.L ? qi : p.L - 1;
+  const bf16* Q = p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qrow * p.q_sl;
+  const bf16* dO = p.dout + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + head * dh;
+  const bf16* Op = p.o + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + head * dh;
+  const bf16* Kb = p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
+  const bf16* Vb = p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const uint8_t* kp = haskp ? p.keypad + (int64_t)b * p.kp_sb : nullptr;
+  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  bf16x8 qf[KS], gf[KS];
+  float dacc = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int d0 = 32 * ks + 8 * kq;
+    qf[ks] = d0 < dh ? *reinterpret_cast<const bf16x8*>(Q + d0) : zero8;
+    gf[ks] = d0 < dh ? *reinterpret_cast<const bf16x8*>(dO + d0) : zero8;
+    const bf16x8 of = d0 < dh ? *reinterpret_cast<const bf16x8*>(Op + d0) : zero8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dacc += (float)of[e] * (float)gf[ks][e];
+  }
+  const float neg_delta = -gen_groups_sum(dacc);
+  const int64_t stat = ((int64_t)b * p.h + head) * p.L + qrow;
+  if (kq == 0 && qi < p.L) p.delta[stat] = neg_delta;
+  const float c = p.scale * LOG2E;
+  const float neg_lse = -p.lse[stat] * LOG2E;
+  f32x4 dq[NDB];
+#pragma unroll
+  for (int n = 0; n < NDB; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int nt = (p.S + 63) / 64;
+  if (causal) nt = max(1, min(nt, (min(p.S, p.start_pos + q0 + 64) + 63) / 64));
+  const unsigned ktr = vy_lds_addr(kt) + (4 * kq + (r16 >> 2)) * PITCH + (4 * (r16 & 3)) * 2;
+  for (int t = 0; t < nt; ++t) {
+    const int k0 = t * 64;
+    bf16x8 kreg[CPT], vreg[CPT];
+    gen_stage<DHP>(kt, Kb, p.k_sl, k0, p.S, dh, tid, kreg);
+    gen_stage<DHP>(vt, Vb, p.v_sl, k0, p.S, dh, tid, vreg);
+    __syncthreads();
+    gen_store<DHP>(kt, tid, kreg);
+    gen_store<DHP>(vt, tid, vreg);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {neg_delta, neg_delta, neg_delta, neg_delta};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (16 * blk + r16) * PITCH + (32 * ks + 8 * kq) * 2);
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt + (16 * blk + r16) * PITCH + (32 * ks + 8 * kq) * 2);
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, gf[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kj = k0 + 16 * blk + 4 * kq + r;
+        bool vis = kj < p.S && qi < p.L;
+        if (causal) vis = vis && kj <= qi + p.start_pos;
+        if (haskp) vis = vis && kp[kj < p.S ? kj : 0] != 0;
+        const float pr = vis ? __builtin_amdgcn_exp2f(fmaf(sc[r], c, neg_lse)) : 0.f;
+        ds[blk][r] = pr * dp[r];
+      }
+    }
+    // dQ^T += K^T dS^T: k-steps of 32 keys = blocks (2 tt, 2 tt + 1) in the order the values sit in
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      bf16x8 sf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sf[r] = (bf16)ds[2 * tt][r]; sf[4 + r] = (bf16)ds[2 * tt + 1][r]; }
+      vy_static_for<NDB>([&](auto n_c) {
+        constexpr int n = decltype(n_c)::value;
+        union { struct { s16x4 a, b; } h; bf16x8 v; } u;
+        u.h.a = vy_lds_tr16_off<n * 32>(ktr + (32 * tt) * PITCH);
+        u.h.b = vy_lds_tr16_off<n * 32>(ktr + (32 * tt + 16) * PITCH);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        vy_tie(u.v);
+        dq[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, sf, dq[n], 0, 0, 0);
+      });
+    }
+  }
+  if (qi < p.L) {
+    bf16* D = p.dq + (int64_t)b * p.dq_sb + (int64_t)head * p.dq_sh + (int64_t)qi * p.dq_sl;
+#pragma unroll
+    for (int n = 0; n < NDB; ++n) {
+      const int d0 = 16 * n + 4 * kq;
+      if (d0 < dh) {
+        bf16x4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = (bf16)(dq[n][r] * p.scale);
+        *reinterpret_cast<bf16x4*>(D + d0) = w;
+      }
+    }
+  }
+}
+
+template <int DHP>
+__global__ __launch_bounds__(256) void attn_bwd_gen_dkdv_kernel(BwdParams p, int dh) {
+  typedef GenBwd<DHP> G;
+  constexpr int PITCH = G::PITCH, KS = G::KS, NDB = G::NDB, CPT = G::CPT;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * PITCH + 2 * 64 * 4];
+  char* qt = smem;
+  char* gt = smem + 64 * PITCH;
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * 64 * PITCH);   // -lse * log2e of the tile's query rows
+  float* del_s = lse_s + 64;                                          // -delta
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kq = lane >> 4;
+  const int kvh = (int)blockIdx.y % p.hk, b = (int)blockIdx.y / p.hk;
+  const int nrep = p.h / p.hk;
+  const int k0 = (int)blockIdx.x * 64;
+  const int kj = k0 + wave * 16 + r16;
+  const int krow = kj < p.S ? kj : p.S - 1;
+  const bf16* Kp = p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh + (int64_t)krow * p.k_sl;
+  const bf16* Vp = p.v + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh + (int64_t)krow * p.v_sl;
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const bool key_vis = kj < p.S && (!haskp || p.keypad[(int64_t)b * p.kp_sb + krow] != 0);
+  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  bf16x8 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int d0 = 32 * ks + 8 * kq;
+    kf[ks] = d0 < dh ? *reinterpret_cast<const bf16x8*>(Kp + d0) : zero8;
+    vf[ks] = d0 < dh ? *reinterpret_cast<const bf16x8*>(Vp + d0) : zero8;
+  }
+  f32x4 dk[NDB], dv[NDB];
+#pragma unroll
+  for (int n = 0; n < NDB; ++n) { dk[n] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[n] = dk[n]; }
+  const float c = p.scale * LOG2E;
+  // query rows that can see a key of this tile: causal => q + start_pos >= k0
+  const int qstart = causal ? max(0, k0 - p.start_pos) & ~63 : 0;
+  const unsigned qtr = vy_lds_addr(qt) + (4 * kq + (r16 >> 2)) * PITCH + (4 * (r16 & 3)) * 2;
+  const unsigned gtr = vy_lds_addr(gt) + (4 * kq + (r16 >> 2)) * PITCH + (4 * (r16 & 3)) * 2;
+  for (int hh = 0; hh < nrep; ++hh) {
+    const int head = kvh * nrep + hh;
+    const bf16* Qb = p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh;
+    const bf16* Gb = p.dout + (int64_t)b * p.o_sb + head * dh;
+    const int64_t stat0 = ((int64_t)b * p.h + head) * p.L;
+    for (int q0 = qstart; q0 < p.L; q0 += 64) {
+      bf16x8 qreg[CPT], greg[CPT];
+      gen_stage<DHP>(qt, Qb, p.q_sl, q0, p.L, dh, tid, qreg);
+      gen_stage<DHP>(gt, Gb, p.o_sl, q0, p.L, dh, tid, greg);
+      float ls = 0.f, dl = 0.f;
+      if (tid < 64) {
+        const int qq = q0 + tid;
+        ls = qq < p.L ? -p.lse[stat0 + qq] * LOG2E : 0.f;
+        dl = qq < p.L ? p.delta[stat0 + qq] : 0.f;
+      }
+      __syncthreads();
+      gen_store<DHP>(qt, tid, qreg);
+      gen_store<DHP>(gt, tid, greg);
+      if (tid < 64) { lse_s[tid] = ls; del_s[tid] = dl; }
+      __syncthreads();
+      // S[q][key] and dP[q][key]: A = Q / dO rows of the tile, B = this lane's key
+      f32x4 pr[4], dsv[4];
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dp[r] = del_s[16 * blk + 4 * kq + r];   // -delta of the lane's query rows
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qt + (16 * blk + r16) * PITCH + (32 * ks + 8 * kq) * 2);
+          const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gt + (16 * blk + r16) * PITCH + (32 * ks + 8 * kq) * 2);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = q0 + 16 * blk + 4 * kq + r;
+          bool vis = key_vis && qq < p.L;
+          if (causal) vis = vis && kj <= qq + p.start_pos;
+          const float pv = vis ? __builtin_amdgcn_exp2f(fmaf(sc[r], c, lse_s[16 * blk + 4 * kq + r])) : 0.f;
+          pr[blk][r] = pv;
+          dsv[blk][r] = pv * dp[r];
+        }
+      }
+      // dV^T += dO^T P, dK^T += Q^T dS: k-steps of 32 query rows = blocks (2 tt, 2 tt + 1)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        bf16x8 pf, sf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[r] = (bf16)pr[2 * tt][r]; pf[4 + r] = (bf16)pr[2 * tt + 1][r];
+          sf[r] = (bf16)dsv[2 * tt][r]; sf[4 + r] = (bf16)dsv[2 * tt + 1][r];
+        }
+        vy_static_for<NDB>([&](auto n_c) {
+          constexpr int n = decltype(n_c)::value;
+          union { struct { s16x4 a, b; } h; bf16x8 v; } ug, uq;
+          ug.h.a = vy_lds_tr16_off<n * 32>(gtr + (32 * tt) * PITCH);
+          ug.h.b = vy_lds_tr16_off<n * 32>(gtr + (32 * tt + 16) * PITCH);
+          uq.h.a = vy_lds_tr16_off<n * 32>(qtr + (32 * tt) * PITCH);
+          uq.h.b = vy_lds_tr16_off<n * 32>(qtr + (32 * tt + 16) * PITCH);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          vy_tie(ug.v); vy_tie(uq.v);
+          dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ug.v, pf, dv[n], 0, 0, 0);
+          dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uq.v, sf, dk[n], 0, 0, 0);
+        });
+      }
+    }
+  }
+  if (kj < p.S) {
+    bf16* DK = p.dk + (int64_t)b * p.dk_sb + (int64_t)kvh * p.dk_sh + (int64_t)kj * p.dk_sl;
+    bf16* DV = p.dv + (int64_t)b * p.dv_sb + (int64_t)kvh * p.dv_sh + (int64_t)kj * p.dv_sl;
+#pragma unroll
+    for (int n = 0; n < NDB; ++n) {
+      const int d0 = 16 * n + 4 * kq;
+      if (d0 < dh) {
+        bf16x4 wk_, wv_;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { wk_[r] = (bf16)(dk[n][r] * p.scale); wv_[r] = (bf16)dv[n][r]; }
+        *reinterpret_cast<bf16x4*>(DK + d0) = wk_;
+        *reinterpret_cast<bf16x4*>(DV + d0) = wv_;
+      }
+    }
+  }
+}
+
 extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl, const void* k,
                            int64_t k_sb, int64_t k_sh, int64_t k_sl, const void* v, int64_t v_sb,
                            int64_t v_sh, int64_t v_sl, const void* out, const void* dout, int64_t o_sb,
@@ -1068,7 +1355,7 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                            int h, int hk, int64_t L, int64_t S, int dh, float scale, int dtype, void* stream) {
   const char* who = "vy_attn_bwd";
   if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only", who);
-  if (dh != 64) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: head_dim %d (only 64 has a backward kernel yet)", who, dh);
+  if (dh != 64 && (dh % 8 || dh > 256 || dh < 8)) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: head_dim %d (multiples of 8 up to 256)", who, dh);
   if (mask_kind & VY_MASK_ADDITIVE) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: generic additive masks have no backward; use causal/key-padding descriptors", who);
   if (!q || !k || !v || !out || !dout || !lse || !delta_ws || !dq || !dk || !dv) VY_FAIL(VY_ERR_ARG, "%s: null tensor", who);
   if (B <= 0 || h <= 0 || hk <= 0 || h % hk || L <= 0 || S <= 0) VY_FAIL(VY_ERR_ARG, "%s: bad sizes", who);
@@ -1092,6 +1379,24 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   if ((cos_tab == nullptr) != (sin_tab == nullptr)) VY_FAIL(VY_ERR_ARG, "%s: cos/sin must both be given", who);
   p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.rope_pos0 = (int)rope_pos0;
   hipStream_t st = (hipStream_t)stream;
+  if (dh != 64) {
+    // other head widths: the general kernels (no fused rotary inverse: dq / dk are rotated back afterwards)
+    const dim3 gq((unsigned)((L + 63) / 64), (unsigned)(h * B), 1), gk((unsigned)((S + 63) / 64), (unsigned)(hk * B), 1), block(256);
+    if (dh <= 96) hipLaunchKernelGGL(attn_bwd_gen_dq_kernel<96>, gq, block, 0, st, p, dh);
+    else if (dh <= 128) hipLaunchKernelGGL(attn_bwd_gen_dq_kernel<128>, gq, block, 0, st, p, dh);
+    else hipLaunchKernelGGL(attn_bwd_gen_dq_kernel<256>, gq, block, 0, st, p, dh);
+    VY_CHECK_LAUNCH("vy_attn_bwd(dq)");
+    if (dh <= 96) hipLaunchKernelGGL(attn_bwd_gen_dkdv_kernel<96>, gk, block, 0, st, p, dh);
+    else if (dh <= 128) hipLaunchKernelGGL(attn_bwd_gen_dkdv_kernel<128>, gk, block, 0, st, p, dh);
+    else hipLaunchKernelGGL(attn_bwd_gen_dkdv_kernel<256>, gk, block, 0, st, p, dh);
+    VY_CHECK_LAUNCH("vy_attn_bwd(dkdv)");
+    if (cos_tab) {
+      const int rc = vy_rope_fwd(dq, dq_sb, dq_sh, dq_sl, cos_tab, sin_tab, rope_pos0, B, h, L, dh, 1, dtype, stream);
+      if (rc != VY_OK) return rc;
+      return vy_rope_fwd(dk, dk_sb, dk_sh, dk_sl, cos_tab, sin_tab, rope_pos0, B, hk, S, dh, 1, dtype, stream);
+    }
+    return VY_OK;
+  }
   // (delta = rowsum(dO * O) is computed by the dQ kernel for its own rows and left in delta_ws for the
   // dK/dV kernel; attn_delta_kernel remains for reference)
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(h * B), (unsigned)((L + 127) / 128), 1), dim3(256), 0, st, p);
