@@ -452,3 +452,48 @@ def test_decoder_layer_at_the_benchmark_size_vs_oracle():
     for n, p in layer.named_parameters():
         e = rel(p.grad, sd[n].grad)
         assert e < 6e-2, (n, e)
+
+
+@pytest.mark.parametrize("d,heads,kv,at", [(512, 4, 2, "gqa"), (288, 4, 4, None), (512, 2, 1, "gqa"), (768, 6, 6, None)])
+def test_decoder_layer_other_head_widths_vs_oracle(d, heads, kv, at):
+    """DecoderLayer forward AND backward with heads of 128 / 72 / 256 / 128 (the general attention kernels of
+    vy_attn.hip / vy_bwd.hip, rotary inverse of dq / dk after them) under a causal + key-padding mask, against fp32
+    autograd through the CPU oracle on the same recipe weights (reference layers/attention.py:75-147, 150-250)."""
+    from vyomai_amd.layers.mask import AttnMask
+    from vyomai_amd.layers.positional_embeddings import RopeSlice, RopeTable
+    from vyomai_amd.models.decoder import DecoderLayer
+    import vyomai_amd as V
+    cfg = V.EncoderConfig(hidden_size=d, num_attention_heads=heads, num_hidden_layers=1, max_position_embeddings=256,
+                          hidden_dropout_prob=0.0)
+    cfg.num_key_value_heads = kv
+    B, L = 3, 150
+    dh = d // heads
+    layer = DecoderLayer(cfg, 0, at)
+    for n, t in layer.state_dict().items():
+        t.copy_(T(recipe.param_value(f"wideheads.{d}.{heads}." + n, tuple(t.shape))))
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    layer = layer.to(DEV).train()
+    x0 = T(recipe.uniform("wideheads.x", (B, L, d))).to(BF)
+    g0 = T(recipe.uniform("wideheads.gout", (B, L, d))).to(BF)
+    x = x0.to(DEV).requires_grad_(True)
+    tab = O.rotary_angles(dh, cfg.max_position_embeddings)
+    kp = torch.ones(B, L, dtype=torch.int64)
+    kp[0, L - 31:] = 0
+    kp[2, L - 5:] = 0
+    mask = AttnMask.from_padding(kp.to(DEV), causal=True, start_pos=0, query_len=L)
+    y, _ = layer(x, mask, RopeSlice(RopeTable(tab), 0, L))
+    (y.float() * g0.to(DEV).float()).sum().backward()
+    torch.cuda.synchronize()
+    xr = x0.float().requires_grad_(True)
+    c = O.Cfg.of(cfg)
+    add = O.decoder_additive_mask(B, L, kp, 0, torch.float32)
+    yr = O.block(sd, "", c, xr, add, tab[:, :L], at == "gqa")
+    (yr * g0.float()).sum().backward()
+
+    def rel(a, b):
+        return float((a.detach().float().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-12))
+    assert rel(y, yr) < 3e-2, rel(y, yr)
+    assert rel(x.grad, xr.grad) < 6e-2, rel(x.grad, xr.grad)
+    for n, p in layer.named_parameters():
+        e = rel(p.grad, sd[n].grad)
+        assert e < 6e-2, (n, e)

@@ -404,9 +404,11 @@ __global__ __launch_bounds__(256) void attn_fwd_gen_kernel(AttnParams p, int dh)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
-  const int head = (int)blockIdx.y % p.h, b = (int)blockIdx.y / p.h;
+  // heads on x (workgroups go to the XCDs round-robin by linear id: every XCD gets whole heads, so a head's K/V stay in
+  // one L2 and -- under a causal mask -- every XCD gets the same mix of short and long rows), long rows first
+  const int head = (int)blockIdx.x % p.h, b = (int)blockIdx.x / p.h;
   const int kvh = head / (p.h / p.hk);
-  const int q0 = (int)blockIdx.x * 64;
+  const int q0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 64;
   const int qi = q0 + wave * 16 + r16;
   const int qrow = qi < p.L ? qi : p.L - 1;
   const bf16* Q = (const bf16*)p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qrow * p.q_sl;
@@ -837,7 +839,7 @@ extern "C" int vy_attn_fwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   static const int gen_on = [] { const char* e = getenv("VY_ATTN_GEN"); return e ? atoi(e) : 1; }();
   if (gen_on && dtype == VY_BF16 && L > 1 && dh % 8 == 0 && dh <= 256 && !(mask_kind & VY_MASK_ADDITIVE)) {
     // other head widths (72 -> 96 columns, ... 256): the general MFMA kernel, 64 query rows per workgroup
-    const dim3 grid((unsigned)((L + 63) / 64), (unsigned)(h * B), 1), block(256);
+    const dim3 grid((unsigned)(h * B), (unsigned)((L + 63) / 64), 1), block(256);
     if (dh <= 96) hipLaunchKernelGGL(attn_fwd_gen_kernel<96>, grid, block, 0, st, p, dh);
     else hipLaunchKernelGGL(attn_fwd_gen_kernel<256>, grid, block, 0, st, p, dh);
     VY_CHECK_LAUNCH(who);

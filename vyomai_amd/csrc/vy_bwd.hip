@@ -1122,9 +1122,10 @@ __global__ __launch_bounds__(256) void attn_bwd_gen_dq_kernel(BwdParams p, int d
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
-  const int head = (int)blockIdx.y % p.h, b = (int)blockIdx.y / p.h;
+  // heads on x, long rows first (see attn_fwd_gen_kernel)
+  const int head = (int)blockIdx.x % p.h, b = (int)blockIdx.x / p.h;
   const int kvh = head / (p.h / p.hk);
-  const int q0 = (int)blockIdx.x * 64;
+  const int q0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 64;
   const int qi = q0 + wave * 16 + r16;
   const int qrow = qi < p.L ? qi : p.L - 1;
   const bf16* Q = p.q + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)qrow * p.q_sl;
@@ -1232,9 +1233,9 @@ __global__ __launch_bounds__(256) void attn_bwd_gen_dkdv_kernel(BwdParams p, int
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, kq = lane >> 4;
-  const int kvh = (int)blockIdx.y % p.hk, b = (int)blockIdx.y / p.hk;
+  const int kvh = (int)blockIdx.x % p.hk, b = (int)blockIdx.x / p.hk;   // KV heads on x; the first key tiles see the most rows
   const int nrep = p.h / p.hk;
-  const int k0 = (int)blockIdx.x * 64;
+  const int k0 = (int)blockIdx.y * 64;
   const int kj = k0 + wave * 16 + r16;
   const int krow = kj < p.S ? kj : p.S - 1;
   const bf16* Kp = p.k + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh + (int64_t)krow * p.k_sl;
@@ -1381,7 +1382,7 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   hipStream_t st = (hipStream_t)stream;
   if (dh != 64) {
     // other head widths: the general kernels (no fused rotary inverse: dq / dk are rotated back afterwards)
-    const dim3 gq((unsigned)((L + 63) / 64), (unsigned)(h * B), 1), gk((unsigned)((S + 63) / 64), (unsigned)(hk * B), 1), block(256);
+    const dim3 gq((unsigned)(h * B), (unsigned)((L + 63) / 64), 1), gk((unsigned)(hk * B), (unsigned)((S + 63) / 64), 1), block(256);
     if (dh <= 96) hipLaunchKernelGGL(attn_bwd_gen_dq_kernel<96>, gq, block, 0, st, p, dh);
     else if (dh <= 128) hipLaunchKernelGGL(attn_bwd_gen_dq_kernel<128>, gq, block, 0, st, p, dh);
     else hipLaunchKernelGGL(attn_bwd_gen_dq_kernel<256>, gq, block, 0, st, p, dh);
