@@ -206,3 +206,103 @@ def test_attention_bwd_fused_rope_inverse(dh):
     check(a[0], b[0], 2e-2, 2e-2, "dq")
     check(a[1], b[1], 2e-2, 2e-2, "dk")
     check(a[2], b[2], 0, 0, "dv")
+
+
+# ---- fp32: the parity path has a backward too (plain-FMA kernels) ---------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(256, 128, 128), (1000, 768, 520), (77, 50265, 64), (4100, 72, 3072)])
+def test_wgrad_fp32(M, N, K):
+    ops = _ops()
+    ld = (N + 7) // 8 * 8
+    dy_full = torch.zeros(M, ld)
+    dy_full[:, :N] = rnd(M, N, seed=1)
+    x = rnd(M, K, seed=2)
+    dyg = dy_full.to(DEV)[:, :N]
+    dw = torch.full((N, K), 7.0, dtype=torch.float32, device=DEV)
+    db = torch.full((N,), 7.0, dtype=torch.float32, device=DEV)
+    ops.linear_wgrad(dyg, x.to(DEV), dw, db, accumulate=False)
+    want = (dy_full[:, :N].double().t() @ x.double())
+    tol = 2e-6 * math.sqrt(M) * 4
+    check(dw, want, tol, 1e-5, "dW fp32")
+    check(db, dy_full[:, :N].double().sum(0), tol, 1e-5, "db fp32")
+    alpha = torch.tensor([0.5], dtype=torch.float32, device=DEV)
+    ops.linear_wgrad(dyg, x.to(DEV), dw, db, accumulate=True, alpha=alpha)
+    check(dw, 1.5 * want, 2 * tol, 1e-5, "dW accumulate with alpha")
+    ops.linear_wgrad_grouped([(dyg, x.to(DEV), dw, None)])
+    check(dw, 2.5 * want, 3 * tol, 1e-5, "grouped entry point, fp32")
+
+
+BWD_F32_CASES = [
+    # B, h, hk, L, S, causal, start, keypad ('right' / 'left' = rows without a visible key), dh
+    (2, 4, 4, 128, 128, True, 0, None, 64),
+    (2, 4, 2, 130, 130, True, 0, "right", 64),
+    (2, 3, 1, 70, 70, False, 0, "right", 64),
+    (2, 4, 2, 100, 100, True, 0, "left", 64),
+    (1, 2, 2, 50, 50, False, 0, "left", 72),
+    (2, 4, 2, 90, 90, True, 0, "right", 128),
+    (1, 2, 1, 65, 65, True, 0, None, 256),
+    (2, 12, 4, 40, 100, True, 60, "right", 64),
+    (2, 2, 2, 33, 77, False, 0, None, 40),
+]
+
+
+@pytest.mark.parametrize("case", BWD_F32_CASES)
+def test_attention_bwd_fp32(case):
+    """fp32 attention backward against fp64 autograd through the reference formulation (scores + additive finfo.min
+    mask, softmax, @ v: layers/attention.py:127-140) at 1e-5 -- including rows without a visible key (left padding under
+    a causal mask; every key padded), whose uniform softmax autograd differentiates like any other."""
+    ops = _ops()
+    B, h, hk, L, S, causal, start, kpk, dh = case
+    q, k, v = rnd(B, h, L, dh, seed=1), rnd(B, hk, S, dh, seed=2), rnd(B, hk, S, dh, seed=3)
+    do = rnd(B, L, h * dh, seed=4)
+    keypad = None
+    if kpk is not None:
+        keypad = torch.ones(B, S, dtype=torch.uint8)
+        if kpk == "right":
+            keypad[0, S - S // 3:] = 0
+            if B > 1:
+                keypad[1, S - 7:] = 0
+        else:
+            keypad[0, : S // 4] = 0          # causal: the first rows of sequence 0 see nothing
+            if not causal:
+                keypad[0, :] = 0             # non-causal: every row of sequence 0 is dead
+    mask = _dense_mask(B, L, S, causal, start, keypad, None)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    s = qd @ O.repeat_kv(kd, h // hk).transpose(-1, -2) / math.sqrt(dh) + mask.double()
+    out_ref = O.merge_heads(torch.softmax(s, -1) @ O.repeat_kv(vd, h // hk))
+    (out_ref * do.double()).sum().backward()
+    qg, kg, vg = q.to(DEV), k.to(DEV), v.to(DEV)
+    kpg = keypad.to(DEV) if keypad is not None else None
+    lse = torch.zeros(B, h, L, dtype=torch.float32, device=DEV)
+    out = ops.attention(qg, kg, vg, causal=causal, start_pos=start, keypad=kpg, lse=lse)
+    W = (h + 2 * hk) * dh
+    packed = torch.zeros(B, max(L, S), W, dtype=torch.float32, device=DEV)
+    dq = packed[:, :L, : h * dh].view(B, L, h, dh).permute(0, 2, 1, 3)
+    dk = packed[:, :S, h * dh:(h + hk) * dh].view(B, S, hk, dh).permute(0, 2, 1, 3)
+    dv = packed[:, :S, (h + hk) * dh:].view(B, S, hk, dh).permute(0, 2, 1, 3)
+    ops.attention_bwd(qg, kg, vg, out, do.to(DEV), lse, dq, dk, dv, causal=causal, start_pos=start, keypad=kpg)
+    check(out, out_ref, 2e-5, 1e-5, "fwd out fp32")
+    check(dq, qd.grad, 3e-5, 1e-4, "dq fp32")
+    check(dk, kd.grad, 3e-5, 1e-4, "dk fp32")
+    check(dv, vd.grad, 3e-5, 1e-4, "dv fp32")
+
+
+def test_attention_bwd_fp32_rope_inverse():
+    ops = _ops()
+    B, h, hk, L, dh = 2, 4, 2, 48, 64
+    q, k, v = rnd(B, h, L, dh, seed=1).to(DEV), rnd(B, hk, L, dh, seed=2).to(DEV), rnd(B, hk, L, dh, seed=3).to(DEV)
+    do = rnd(B, L, h * dh, seed=4).to(DEV)
+    cos, sin = ops.rope_tables(dh, 64, DEV)
+    lse = torch.zeros(B, h, L, dtype=torch.float32, device=DEV)
+    out = ops.attention(q, k, v, causal=True, lse=lse)
+    res = []
+    for fused in (True, False):
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+        if fused:
+            ops.attention_bwd(q, k, v, out, do, lse, dq, dk, dv, causal=True, cos=cos, sin=sin, rope_pos0=3)
+        else:
+            ops.attention_bwd(q, k, v, out, do, lse, dq, dk, dv, causal=True)
+            ops.rope_(dq, cos, sin, 3, inverse=True)
+            ops.rope_(dk, cos, sin, 3, inverse=True)
+        res.append((dq, dk, dv))
+    for a, b_ in zip(*res):
+        assert torch.equal(a, b_)

@@ -497,3 +497,38 @@ def test_decoder_layer_other_head_widths_vs_oracle(d, heads, kv, at):
     for n, p in layer.named_parameters():
         e = rel(p.grad, sd[n].grad)
         assert e < 6e-2, (n, e)
+
+
+@pytest.mark.parametrize("at", [None, "gqa"])
+def test_layer_gradients_fp32_vs_reference(golden, at):
+    """The same decoder layer as test_layer_gradients_vs_reference, run in fp32 end to end (forward AND backward on the
+    plain-FMA kernels): output and every gradient against the REAL reference's autograd (tests/golden/grads.npz) at
+    fp32 tolerance -- the backward arithmetic itself is pinned, not only its bf16 rendering."""
+    from vyomai_amd.layers.mask import AttnMask
+    from vyomai_amd.layers.positional_embeddings import RopeSlice, RopeTable
+    from vyomai_amd.models.decoder import DecoderLayer
+    g = golden("grads")
+    tag = "wide"
+    cfg = cases.wide_cfg()
+    cfg.hidden_dropout_prob = 0.0
+    B, L = cases.MODULE_BL[tag]
+    d = cfg.hidden_size
+    dh = d // cfg.num_attention_heads
+    layer = DecoderLayer(cfg, 0, at)
+    for n, t in layer.state_dict().items():
+        t.copy_(T(recipe.param_value(f"{tag}.layer.{at}." + n, tuple(t.shape))))
+    layer = layer.to(DEV).train()
+    x = T(recipe.uniform(f"{tag}.x", (B, L, d))).to(DEV).requires_grad_(True)
+    gout = T(recipe.uniform(f"{tag}.gout", (B, L, d))).to(DEV)
+    mask = AttnMask.from_padding(T(cases.keypad(B, L)).to(DEV), causal=True, start_pos=0, query_len=L)
+    freqs = RopeSlice(RopeTable(O.rotary_angles(dh, cfg.max_position_embeddings)), 0, L)
+    y, _ = layer(x, mask, freqs)
+    assert y.dtype == torch.float32
+    (y * gout).sum().backward()
+    assert rel_err(y, g[f"{tag}.{at}.y"]) < 2e-5, rel_err(y, g[f"{tag}.{at}.y"])
+    assert rel_err(x.grad, g[f"{tag}.{at}.dx"]) < 1e-4, rel_err(x.grad, g[f"{tag}.{at}.dx"])
+    for n, p in layer.named_parameters():
+        want = g[f"{tag}.{at}.d.{n}"]
+        got = p.grad if p.grad.numel() <= 4096 else cases.sub2(p.grad)
+        e = rel_err(got, want)
+        assert e < 1e-4, (n, e)

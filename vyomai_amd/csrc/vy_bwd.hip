@@ -939,14 +939,98 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(BwdParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// fp32 weight gradient (the 1e-5 parity path trains too): dW[n][k] += alpha * sum_m dY[m][n] X[m][k], plain FMAs --
+// 64 x 64 output tile per workgroup, 4 x 4 per thread, rows in steps of 16 through LDS, M split over workgroups that
+// add into dW with fp32 atomics (dW is zeroed first when beta = 0).  The bias gradient is the column sum of the same
+// dY tiles, taken by the k-tile-0 workgroups while they stage them.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_tn_f32_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                           const float* __restrict__ X, int64_t ldx, float* dW, int64_t lddw,
+                                                           float* db, const float* alpha_dev, int M, int N, int K, int tiles_k,
+                                                           int tiles, int m_chunk) {
+  __shared__ float sy[16][64], sx[16][64];
+  __shared__ float sb[4][64];
+  const int tid = threadIdx.x;
+  const int tile = (int)blockIdx.x % tiles, split = (int)blockIdx.x / tiles;
+  const int n0 = (tile / tiles_k) * 64, k0 = (tile % tiles_k) * 64;
+  const int m_begin = split * m_chunk, m_end = min(M, m_begin + m_chunk);
+  const int tx = tid & 15, ty = tid >> 4;      // k / n micro-tile of the thread
+  const int lc = tid & 63, lr = tid >> 6;      // staging: column, row group
+  float acc[4][4] = {};
+  float colsum = 0.f;
+  for (int m0 = m_begin; m0 < m_end; m0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * i + lr, m = m0 + r;
+      const bool ok = m < m_end;
+      const float yv = ok && n0 + lc < N ? dY[(int64_t)m * lddy + n0 + lc] : 0.f;
+      sy[r][lc] = yv;
+      colsum += yv;
+      sx[r][lc] = ok && k0 + lc < K ? X[(int64_t)m * ldx + k0 + lc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&sy[kk][4 * ty]);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&sx[kk][4 * tx]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  const float alpha = alpha_dev ? *alpha_dev : 1.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + 4 * ty + i;
+    if (n >= N) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 4 * tx + j;
+      if (k < K) atomicAdd(dW + (int64_t)n * lddw + k, alpha * acc[i][j]);
+    }
+  }
+  if (db && k0 == 0) {
+    sb[lr][lc] = colsum;
+    __syncthreads();
+    if (tid < 64 && n0 + tid < N) atomicAdd(db + n0 + tid, alpha * (sb[0][tid] + sb[1][tid] + sb[2][tid] + sb[3][tid]));
+  }
+}
+
+int wgrad_f32(const char* who, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, float* db,
+              float beta, const float* alpha_dev, int64_t M, int64_t N, int64_t K, hipStream_t st) {
+  if (beta == 0.f) {
+    if (hipMemset2DAsync(dw, lddw * sizeof(float), 0, K * sizeof(float), N, st) != hipSuccess)
+      VY_FAIL(VY_ERR_LAUNCH, "%s: memset failed", who);
+    if (db && hipMemsetAsync(db, 0, N * sizeof(float), st) != hipSuccess) VY_FAIL(VY_ERR_LAUNCH, "%s: memset failed", who);
+  }
+  const int tiles_k = (int)vy_cdiv(K, 64), tiles = (int)vy_cdiv(N, 64) * tiles_k;
+  int64_t splits = vy_cdiv(1024, tiles);
+  const int64_t max_splits = vy_cdiv(M, 64);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int64_t m_chunk = vy_cdiv(vy_cdiv(M, splits), 16) * 16;
+  splits = vy_cdiv(M, m_chunk);
+  hipLaunchKernelGGL(wgrad_tn_f32_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, st, (const float*)dy, lddy,
+                     (const float*)x, ldx, dw, lddw, db, alpha_dev, (int)M, (int)N, (int)K, tiles_k, tiles, (int)m_chunk);
+  VY_CHECK_LAUNCH(who);
+  return VY_OK;
+}
+
 }  // namespace
 
 extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
                                int64_t lddw, float* db, float beta, const float* alpha_dev, int64_t M,
                                int64_t N, int64_t K, int dtype, void* stream) {
   const char* who = "vy_linear_wgrad";
-  if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only (fp32 is the inference parity path)", who);
+  if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
   if (!dy || !x || !dw || M <= 0 || N <= 0 || K <= 0) VY_FAIL(VY_ERR_ARG, "%s: bad arguments", who);
+  if (dtype == VY_F32) {
+    if (beta != 0.f && beta != 1.f) VY_FAIL(VY_ERR_ARG, "%s: beta must be 0 or 1", who);
+    return wgrad_f32(who, dy, lddy, x, ldx, dw, lddw, db, beta, alpha_dev, M, N, K, (hipStream_t)stream);
+  }
   // N may be odd (vocabulary) as long as every dY row is readable up to the next multiple of 8
   if (K % 8 || lddy % 8 || ldx % 8 || lddy < vy_cdiv(N, 8) * 8 || (uintptr_t)dy % 16 || (uintptr_t)x % 16)
     VY_FAIL(VY_ERR_ARG, "%s: K and leading dimensions must be multiples of 8 (lddy >= roundup8(N)), operands 16-byte aligned", who);
@@ -1012,8 +1096,16 @@ extern "C" int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int6
 
 extern "C" int vy_linear_wgrad_grouped(const vy_wgrad_desc* descs, int32_t n, int dtype, void* stream) {
   const char* who = "vy_linear_wgrad_grouped";
-  if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only", who);
+  if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
   if (!descs || n <= 0 || n > 8) VY_FAIL(VY_ERR_ARG, "%s: 1..8 descriptors", who);
+  if (dtype == VY_F32) {   // the parity path: one plain launch per descriptor
+    for (int i = 0; i < n; ++i) {
+      const vy_wgrad_desc& d = descs[i];
+      if (!d.dy || !d.x || !d.dw || d.M <= 0 || d.N <= 0 || d.K <= 0) VY_FAIL(VY_ERR_ARG, "%s: descriptor %d: bad arguments", who, i);
+      if (int rc = wgrad_f32(who, d.dy, d.lddy, d.x, d.ldx, d.dw, d.lddw, d.db, 1.f, nullptr, d.M, d.N, d.K, (hipStream_t)stream)) return rc;
+    }
+    return VY_OK;
+  }
   int64_t tiles_total = 0;
   for (int i = 0; i < n; ++i) {
     const vy_wgrad_desc& d = descs[i];
@@ -1345,6 +1437,209 @@ __global__ __launch_bounds__(256) void attn_bwd_gen_dkdv_kernel(BwdParams p, int
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// fp32 attention backward (any head width up to 256; the parity path -- plain FMAs, expf, no atomics):
+//   dq kernel:    16 query rows per workgroup, keys in chunks of 64.  Phase A, thread (row, 4 keys): s = q . k,
+//                 dp = dO . v, P = exp(s * scale - lse), dS = P (dp - delta) -> LDS.  Phase B, thread (row, every
+//                 16th column): dq += dS K.  delta = rowsum(dO o O) is computed here and left in delta_ws.
+//   dk/dv kernel: 16 keys per workgroup, the query heads of the KV group and their rows in chunks of 64; the same two
+//                 phases with the roles exchanged: dv += P^T dO, dk += dS^T Q.
+// A row without a visible key got the reference's uniform softmax over ALL keys in the forward (scores +
+// finfo.min collapse to finfo.min: attention.py:133-137) and autograd differentiates exactly that: P = 1 / S for every
+// key of such a row (its lse is ~ -FLT_MAX).
+// ------------------------------------------------------------------------------------------
+constexpr int F32_PITCH = 260;
+__device__ __forceinline__ float f32_prob(bool dead, bool vis, bool in_range, float s, float scale, float lse, float inv_s) {
+  if (dead) return in_range ? inv_s : 0.f;
+  return vis ? expf(fmaf(s, scale, -lse)) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_f32_dq_kernel(BwdParams p, int dh) {
+  __shared__ __attribute__((aligned(16))) float sq[16][F32_PITCH], sg[16][F32_PITCH];
+  __shared__ float sds[16][65];
+  __shared__ float s_lse[16], s_del[16];
+  const float* Qp = reinterpret_cast<const float*>(p.q);
+  const float* Kp = reinterpret_cast<const float*>(p.k);
+  const float* Vp = reinterpret_cast<const float*>(p.v);
+  const float* Op = reinterpret_cast<const float*>(p.o);
+  const float* Gp = reinterpret_cast<const float*>(p.dout);
+  const int tid = threadIdx.x;
+  const int head = (int)blockIdx.x % p.h, b = (int)blockIdx.x / p.h;
+  const int kvh = head / (p.h / p.hk);
+  const int q0 = (int)blockIdx.y * 16;
+  const float* Kb = Kp + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh;
+  const float* Vb = Vp + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh;
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const uint8_t* kp = haskp ? p.keypad + (int64_t)b * p.kp_sb : nullptr;
+  const int r = tid >> 4, c = tid & 15;
+  const int qi = q0 + r;
+  const int64_t stat = ((int64_t)b * p.h + head) * p.L + (qi < p.L ? qi : p.L - 1);
+  {
+    float part = 0.f;
+    const float* Qr = Qp + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh + (int64_t)(qi < p.L ? qi : 0) * p.q_sl;
+    const float* Gr = Gp + (int64_t)b * p.o_sb + (int64_t)(qi < p.L ? qi : 0) * p.o_sl + head * dh;
+    const float* Or = Op + (int64_t)b * p.o_sb + (int64_t)(qi < p.L ? qi : 0) * p.o_sl + head * dh;
+    for (int d = c; d < F32_PITCH; d += 16) {
+      const bool ok = d < dh && qi < p.L;
+      const float g = ok ? Gr[d] : 0.f;
+      sq[r][d] = ok ? Qr[d] : 0.f;
+      sg[r][d] = g;
+      part += ok ? g * Or[d] : 0.f;
+    }
+#pragma unroll
+    for (int o_ = 8; o_ > 0; o_ >>= 1) part += __shfl_xor(part, o_, 64);
+    if (c == 0) {
+      s_del[r] = part;
+      s_lse[r] = qi < p.L ? p.lse[stat] : 0.f;
+      if (qi < p.L) p.delta[stat] = part;
+    }
+  }
+  __syncthreads();
+  const float lse = s_lse[r], delta = s_del[r];
+  const bool dead = haskp && lse < -1e37f;
+  const float inv_s = 1.f / (float)p.S;
+  float dq[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+  // with key padding every key is walked (dead rows); pure causal stops at the block's diagonal
+  const int s_hi = causal && !haskp ? min(p.S, p.start_pos + q0 + 16) : p.S;
+  const int dh4 = (dh + 3) & ~3;   // the LDS rows are zero beyond dh; global rows are read in float4s up to roundup4(dh) <= row stride
+  for (int k0 = 0; k0 < s_hi; k0 += 64) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int kj = k0 + 4 * c + e;
+      const int kjc = kj < p.S ? kj : p.S - 1;
+      const float* Kr = Kb + (int64_t)kjc * p.k_sl;
+      const float* Vr = Vb + (int64_t)kjc * p.v_sl;
+      float s = 0.f, dp = 0.f;
+      for (int d = 0; d < dh4; d += 4) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(Kr + d), vv = *reinterpret_cast<const f32x4*>(Vr + d);
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(&sq[r][d]), gv = *reinterpret_cast<const f32x4*>(&sg[r][d]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { s = fmaf(qv[t], kv[t], s); dp = fmaf(gv[t], vv[t], dp); }
+      }
+      bool vis = kj < p.S && qi < p.L;
+      if (causal) vis = vis && kj <= qi + p.start_pos;
+      if (haskp) vis = vis && kp[kjc] != 0;
+      const float pr = f32_prob(dead, vis, kj < p.S && qi < p.L, s, p.scale, lse, inv_s);
+      sds[r][4 * c + e] = pr * (dp - delta);
+    }
+    __syncthreads();
+    const int jn = min(64, p.S - k0);
+    for (int j = 0; j < jn; ++j) {
+      const float w = sds[r][j];
+      const float* Kr = Kb + (int64_t)(k0 + j) * p.k_sl;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int d = c + 16 * i;
+        if (d < dh) dq[i] = fmaf(w, Kr[d], dq[i]);
+      }
+    }
+    __syncthreads();
+  }
+  if (qi < p.L) {
+    float* D = reinterpret_cast<float*>(p.dq) + (int64_t)b * p.dq_sb + (int64_t)head * p.dq_sh + (int64_t)qi * p.dq_sl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int d = c + 16 * i;
+      if (d < dh) D[d] = dq[i] * p.scale;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_f32_dkdv_kernel(BwdParams p, int dh) {
+  __shared__ __attribute__((aligned(16))) float sk[16][F32_PITCH], sv[16][F32_PITCH];
+  __shared__ float sp[16][65], sds[16][65];
+  __shared__ float s_lse[64], s_del[64];
+  const float* Qp = reinterpret_cast<const float*>(p.q);
+  const float* Kp = reinterpret_cast<const float*>(p.k);
+  const float* Vp = reinterpret_cast<const float*>(p.v);
+  const float* Gp = reinterpret_cast<const float*>(p.dout);
+  const int tid = threadIdx.x;
+  const int kvh = (int)blockIdx.x % p.hk, b = (int)blockIdx.x / p.hk;
+  const int nrep = p.h / p.hk;
+  const int k0 = (int)blockIdx.y * 16;
+  const bool causal = p.mask_kind & VY_MASK_CAUSAL;
+  const bool haskp = p.mask_kind & VY_MASK_KEYPAD;
+  const int r = tid >> 4, c = tid & 15;
+  const int kj = k0 + r;
+  const int kjc = kj < p.S ? kj : p.S - 1;
+  {
+    const float* Kr = Kp + (int64_t)b * p.k_sb + (int64_t)kvh * p.k_sh + (int64_t)kjc * p.k_sl;
+    const float* Vr = Vp + (int64_t)b * p.v_sb + (int64_t)kvh * p.v_sh + (int64_t)kjc * p.v_sl;
+    for (int d = c; d < F32_PITCH; d += 16) {
+      const bool ok = d < dh && kj < p.S;
+      sk[r][d] = ok ? Kr[d] : 0.f;
+      sv[r][d] = ok ? Vr[d] : 0.f;
+    }
+  }
+  const bool key_vis = kj < p.S && (!haskp || p.keypad[(int64_t)b * p.kp_sb + kjc] != 0);
+  const float inv_s = 1.f / (float)p.S;
+  float dk[16], dv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+  const int qstart = causal && !haskp ? max(0, k0 - p.start_pos) & ~63 : 0;
+  const int dh4 = (dh + 3) & ~3;
+  for (int hh = 0; hh < nrep; ++hh) {
+    const int head = kvh * nrep + hh;
+    const float* Qb = Qp + (int64_t)b * p.q_sb + (int64_t)head * p.q_sh;
+    const float* Gb = Gp + (int64_t)b * p.o_sb + head * dh;
+    const int64_t stat0 = ((int64_t)b * p.h + head) * p.L;
+    for (int q0 = qstart; q0 < p.L; q0 += 64) {
+      __syncthreads();   // the previous chunk's phase B has read sp / sds / (first trip: sk / sv are written)
+      if (tid < 64) {
+        const int qq = q0 + tid;
+        s_lse[tid] = qq < p.L ? p.lse[stat0 + qq] : 0.f;
+        s_del[tid] = qq < p.L ? p.delta[stat0 + qq] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ql = 4 * c + e, qq = q0 + ql;
+        const int qc = qq < p.L ? qq : p.L - 1;
+        const float* Qr = Qb + (int64_t)qc * p.q_sl;
+        const float* Gr = Gb + (int64_t)qc * p.o_sl;
+        float s = 0.f, dp = 0.f;
+        for (int d = 0; d < dh4; d += 4) {
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(Qr + d), gv = *reinterpret_cast<const f32x4*>(Gr + d);
+          const f32x4 kv = *reinterpret_cast<const f32x4*>(&sk[r][d]), vv = *reinterpret_cast<const f32x4*>(&sv[r][d]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { s = fmaf(qv[t], kv[t], s); dp = fmaf(gv[t], vv[t], dp); }
+        }
+        const float lse = s_lse[ql];
+        const bool dead = haskp && lse < -1e37f;
+        bool vis = key_vis && qq < p.L;
+        if (causal) vis = vis && kj <= qq + p.start_pos;
+        const float pr = f32_prob(dead, vis, kj < p.S && qq < p.L, s, p.scale, lse, inv_s);
+        sp[r][ql] = pr;
+        sds[r][ql] = pr * (dp - s_del[ql]);
+      }
+      __syncthreads();
+      const int jn = min(64, p.L - q0);
+      for (int j = 0; j < jn; ++j) {
+        const float pw = sp[r][j], dw_ = sds[r][j];
+        const float* Qr = Qb + (int64_t)(q0 + j) * p.q_sl;
+        const float* Gr = Gb + (int64_t)(q0 + j) * p.o_sl;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int d = c + 16 * i;
+          if (d < dh) { dv[i] = fmaf(pw, Gr[d], dv[i]); dk[i] = fmaf(dw_, Qr[d], dk[i]); }
+        }
+      }
+    }
+  }
+  if (kj < p.S) {
+    float* DK = reinterpret_cast<float*>(p.dk) + (int64_t)b * p.dk_sb + (int64_t)kvh * p.dk_sh + (int64_t)kj * p.dk_sl;
+    float* DV = reinterpret_cast<float*>(p.dv) + (int64_t)b * p.dv_sb + (int64_t)kvh * p.dv_sh + (int64_t)kj * p.dv_sl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int d = c + 16 * i;
+      if (d < dh) { DK[d] = dk[i] * p.scale; DV[d] = dv[i]; }
+    }
+  }
+}
+
 extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl, const void* k,
                            int64_t k_sb, int64_t k_sh, int64_t k_sl, const void* v, int64_t v_sb,
                            int64_t v_sh, int64_t v_sl, const void* out, const void* dout, int64_t o_sb,
@@ -1355,7 +1650,7 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
                            const float* cos_tab, const float* sin_tab, int64_t rope_pos0, int64_t B,
                            int h, int hk, int64_t L, int64_t S, int dh, float scale, int dtype, void* stream) {
   const char* who = "vy_attn_bwd";
-  if (dtype != VY_BF16) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: bf16 only", who);
+  if (dtype != VY_BF16 && dtype != VY_F32) VY_FAIL(VY_ERR_ARG, "%s: bad dtype %d", who, dtype);
   if (dh != 64 && (dh % 8 || dh > 256 || dh < 8)) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: head_dim %d (multiples of 8 up to 256)", who, dh);
   if (mask_kind & VY_MASK_ADDITIVE) VY_FAIL(VY_ERR_UNSUPPORTED, "%s: generic additive masks have no backward; use causal/key-padding descriptors", who);
   if (!q || !k || !v || !out || !dout || !lse || !delta_ws || !dq || !dk || !dv) VY_FAIL(VY_ERR_ARG, "%s: null tensor", who);
@@ -1380,6 +1675,20 @@ extern "C" int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_
   if ((cos_tab == nullptr) != (sin_tab == nullptr)) VY_FAIL(VY_ERR_ARG, "%s: cos/sin must both be given", who);
   p.cos_tab = cos_tab; p.sin_tab = sin_tab; p.rope_pos0 = (int)rope_pos0;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == VY_F32) {
+    // the parity path: plain fp32 kernels (the BwdParams pointers are fp32 here), rotary inverse afterwards
+    const dim3 gq((unsigned)(h * B), (unsigned)((L + 15) / 16), 1), gk((unsigned)(hk * B), (unsigned)((S + 15) / 16), 1), block(256);
+    hipLaunchKernelGGL(attn_bwd_f32_dq_kernel, gq, block, 0, st, p, dh);
+    VY_CHECK_LAUNCH("vy_attn_bwd(dq)");
+    hipLaunchKernelGGL(attn_bwd_f32_dkdv_kernel, gk, block, 0, st, p, dh);
+    VY_CHECK_LAUNCH("vy_attn_bwd(dkdv)");
+    if (cos_tab) {
+      const int rc = vy_rope_fwd(dq, dq_sb, dq_sh, dq_sl, cos_tab, sin_tab, rope_pos0, B, h, L, dh, 1, dtype, stream);
+      if (rc != VY_OK) return rc;
+      return vy_rope_fwd(dk, dk_sb, dk_sh, dk_sl, cos_tab, sin_tab, rope_pos0, B, hk, S, dh, 1, dtype, stream);
+    }
+    return VY_OK;
+  }
   if (dh != 64) {
     // other head widths: the general kernels (no fused rotary inverse: dq / dk are rotated back afterwards)
     const dim3 gq((unsigned)(h * B), (unsigned)((L + 63) / 64), 1), gk((unsigned)(hk * B), (unsigned)((S + 63) / 64), 1), block(256);
