@@ -291,7 +291,8 @@ class FlatTrainer:
         for m in model.modules():
             if hasattr(m, "compute_dtype"):
                 m.compute_dtype = compute_dtype
-        self.arena = FlatArena(model, shadow_dtype=compute_dtype)
+        # fp32 compute (the parity path) reads the masters themselves: no shadow arena
+        self.arena = FlatArena(model, shadow_dtype=None if compute_dtype == torch.float32 else compute_dtype)
         self.m = torch.zeros_like(self.arena.master)
         self.v = torch.zeros_like(self.arena.master)
         self.reducer = BucketReducer(self.arena, process_group, bucket_bytes, comm_dtype=grad_comm_dtype)
