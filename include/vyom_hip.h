@@ -164,7 +164,9 @@ int vy_linear_dgrad(const void* dy, int64_t lddy, const void* wt, int64_t ldwt, 
 
 /* dW[N,K] (fp32, accumulate when beta != 0) = alpha * dY[M,N]^T . X[M,K];  db[N] (fp32) likewise
  * alpha * colsum(dY).  alpha_dev: optional DEVICE fp32 scalar (NULL = 1), e.g. the upstream
- * gradient of a loss whose unit gradient is already stored in dY -- no host sync to read it. */
+ * gradient of a loss whose unit gradient is already stored in dY -- no host sync to read it.
+ * dtype VY_BF16: MFMA kernels (K, lddy, ldx multiples of 8).  VY_F32: the parity path, plain FMAs
+ * (any K; the reference's autograd of nn.Linear in full precision). */
 int vy_linear_wgrad(const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
                     int64_t lddw, float* db, float beta, const float* alpha_dev, int64_t M, int64_t N,
                     int64_t K, int dtype, void* stream);
@@ -196,7 +198,12 @@ int vy_layernorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, c
  * delta_ws: fp32 [B,h,L] scratch.  dk/dv are (B,hk,S,dh): the n_rep query heads of one kv head
  * are summed in-kernel.  Same mask descriptor as the forward.  cos_tab/sin_tab (nullable): when
  * q/k were rotated by RoPE (row rope_pos0 + token of the tables), the inverse rotation is applied
- * to dq and dk in the epilogues, so they are gradients w.r.t. the un-rotated projections. */
+ * to dq and dk (in the epilogues at dh = 64 bf16, by rotation launches otherwise), so they are
+ * gradients w.r.t. the un-rotated projections.
+ * bf16: dh = 64 (tuned kernels) or any multiple of 8 up to 256 (general MFMA kernels; SigLIP's 72 runs
+ * as 96 columns).  fp32: the parity path (plain FMAs, expf), dh a multiple of 8 up to 256 -- there a
+ * row without a visible key is differentiated as the uniform softmax the forward returned for it
+ * (reference layers/attention.py:133-137 under autograd); the bf16 kernels give such rows no gradient. */
 int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl,
                 const void* k, int64_t k_sb, int64_t k_sh, int64_t k_sl,
                 const void* v, int64_t v_sb, int64_t v_sh, int64_t v_sl,

@@ -87,6 +87,11 @@ __global__ __launch_bounds__(256, DH == 64 ? 3 : 1) void attn_fwd_mfma_kernel(At
 
   // LDS-DMA source geometry: piece pc covers LDS bytes [pc*1024, +1024); lane byte P
   int ld_row[NP], ld_koff[NP], ld_voff[NP];
+  // per-lane source pointers of tile 0 (rows clamped to the last key): a full tile adds a wave-uniform offset to them --
+  // two 64-bit adds per piece instead of the clamp + 64-bit multiplies by the row strides (12 quarter-rate multiplies per
+  // tile and wave in a loop that is bound by vector issue)
+  const bf16* ksrc0[NP];
+  const bf16* vsrc0[NP];
 #pragma unroll
   for (int t = 0; t < NP; ++t) {
     const int P = (wave * NP + t) * 1024 + lane * 16;
@@ -96,9 +101,24 @@ __global__ __launch_bounds__(256, DH == 64 ? 3 : 1) void attn_fwd_mfma_kernel(At
     ld_row[t] = row;
     ld_koff[t] = ((((off >> 4) ^ ksw) << 4)) >> 1;  // element offset inside the row
     ld_voff[t] = (off ^ vsw) >> 1;
+    const int r0 = row < p.S ? row : p.S - 1;
+    ksrc0[t] = Kb + (int64_t)r0 * p.k_sl + ld_koff[t];
+    vsrc0[t] = Vb + (int64_t)r0 * p.v_sl + ld_voff[t];
   }
+  const int64_t k_tile = 64 * p.k_sl, v_tile = 64 * p.v_sl;   // elements per 64-key tile
   auto stage = [&](int tile, int buf) {
     const int k0 = tile * 64;
+    if (k0 + 64 <= p.S) {   // wave-uniform: every row of the tile exists
+      const int64_t ko = (int64_t)tile * k_tile, vo = (int64_t)tile * v_tile;
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(ksrc0[t] + ko),
+                                         (VY_LDS void*)(smem + buf * TILE + (wave * NP + t) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(vsrc0[t] + vo),
+                                         (VY_LDS void*)(smem + (NS + buf) * TILE + (wave * NP + t) * 1024), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
       int kr = k0 + ld_row[t];
@@ -118,6 +138,9 @@ __global__ __launch_bounds__(256, DH == 64 ? 3 : 1) void attn_fwd_mfma_kernel(At
   const int v_sw = (RB == 128) ? (((li >> 3) & 1) << 6) : (((li >> 2) & 3) << 6);
   const int v_lane_row = 4 * fh + (li >> 2);            // + 32kb + 16s + 8u
   const int v_lane_off = 32 * g16 + 8 * (li & 3);       // + 64n, then ^ v_sw
+  unsigned k_lds[KS];  // LDS byte address of this lane's K fragment of k-step ks (key row fr, buffer 0)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_lds[ks] = vy_lds_addr(smem) + fr * RB + (((2 * ks + fh) ^ k_sw) << 4);
   unsigned v_lds[ND];  // LDS byte address of V^T fragment column n, row v_lane_row, buffer 0 of the K ring
 #pragma unroll
   for (int n = 0; n < ND; ++n) v_lds[n] = vy_lds_addr(smem) + v_lane_row * RB + ((64 * n + v_lane_off) ^ v_sw);
@@ -164,33 +187,43 @@ __global__ __launch_bounds__(256, DH == 64 ? 3 : 1) void attn_fwd_mfma_kernel(At
     const char* kb_ = smem + buf * TILE;
     const char* vb_ = smem + (NS + buf) * TILE;
     f32x16 st[2];
-    // all K fragments of the tile are requested before the first MFMA (one exposed LDS latency per
-    // tile instead of one per k-step)
-    bf16x8 kfr[2][KS];
+    // Hidden (asm) LDS reads retired by COUNTED waits: the 2 KS K fragments are requested first; MFMA i waits for
+    // fragment i only (lgkmcnt counts in order) and the V^T fragments are requested two at a time behind each QK^T
+    // MFMA, so they land under the remaining MFMAs and the softmax.  (With compiler-visible K reads every QK^T MFMA
+    // sat behind an lgkmcnt(0) that also drained the V^T reads just issued.)
+    bf16x8 kfr[2 * KS];
+    unsigned ka[KS];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        kfr[kb][ks] = *reinterpret_cast<const bf16x8*>(kb_ + (32 * kb + fr) * RB + (((2 * ks + fh) ^ k_sw) << 4));
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][ks], qf[ks], st[kb], 0, 0, 0);
-    }
-    // V^T fragments: asm transposing reads (see vy_common.h), ALL requested here so that they land
-    // under the softmax arithmetic below and the P.V MFMAs run back to back.  One base address per
-    // 32-wide d block; key block, k-step and the +8 row go into the offset field.
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = k_lds[ks] + buf * TILE;
+    vy_static_for<2 * KS>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      kfr[i] = vy_lds_read128_off<(i / KS) * 32 * RB>(ka[i % KS]);
+    });
     unsigned vbase[ND];
 #pragma unroll
     for (int n = 0; n < ND; ++n) vbase[n] = v_lds[n] + buf * TILE;
     bf16x8 vfr[4 * ND];
-    vy_static_for<4 * ND>([&](auto f_c) {
+    auto vread = [&](auto f_c) {
       constexpr int f = decltype(f_c)::value;
-      constexpr int n = f >> 2, kb = (f >> 1) & 1, s = f & 1;
-      vfr[f] = vy_lds_tr16_pair_off<NS * TILE + (32 * kb + 16 * s) * RB, NS * TILE + (32 * kb + 16 * s + 8) * RB>(vbase[n]);
+      if constexpr (f < 4 * ND) {
+        constexpr int n = f >> 2, kb = (f >> 1) & 1, s_ = f & 1;
+        vfr[f] = vy_lds_tr16_pair_off<NS * TILE + (32 * kb + 16 * s_) * RB, NS * TILE + (32 * kb + 16 * s_ + 8) * RB>(vbase[n]);
+      }
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[0][r] = 0.f; st[1][r] = 0.f; }
+    // V^T requests per QK^T MFMA: 4 ND fragments (two ds_read_b64_tr each) spread over the 2 KS MFMAs
+    constexpr int VPM = (4 * ND + 2 * KS - 1) / (2 * KS);
+    // (lgkmcnt is a 4-bit counter: where the exact count exceeds 15 the wait is for 15, i.e. stricter -- dh = 128)
+    vy_static_for<2 * KS>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      // outstanding before this wait: K fragments i .. 2KS-1 and the 2 VPM i tr reads issued so far
+      constexpr int allow = (2 * KS - 1 - i) + 2 * VPM * i;
+      if constexpr (allow <= 15) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(allow) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+      vy_tie(kfr[i]);
+      st[i / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[i], qf[i % KS], st[i / KS], 0, 0, 0);
+      vy_static_for<VPM>([&](auto j_c) { vread(std::integral_constant<int, i * VPM + decltype(j_c)::value>{}); });
     });
     unsigned long long vis = ~0ull;
     if (haskp) vis = kpbits[tile];
