@@ -555,6 +555,12 @@ def test_trainer_fp32_follows_oracle_training():
     ids = T(recipe.token_ids("train.ids", (4, 48), 3, cfg.vocab_size))
     labels = ids.clone()
     labels[0, 40:] = -100
+    # a bf16 trainer alive in the same process (the W^T registry of the dgrad GEMMs is shared: one refresh launch per dtype)
+    m16 = V.DecoderModel(cfg, "rope", None)
+    recipe.load_recipe_(m16)
+    m16 = m16.to(DEV).train()
+    tr16 = FlatTrainer(m16, lr=1e-3, weight_decay=0.01)
+    tr16.train_step(lambda: m16.clm_loss(ids.to(DEV), labels.to(DEV)))
     tr = FlatTrainer(m, lr=1e-3, weight_decay=0.01, compute_dtype=torch.float32)
     assert tr.arena.shadow is None
     opt = torch.optim.AdamW(list(sd.values()), lr=1e-3, weight_decay=0.01)
@@ -567,6 +573,7 @@ def test_trainer_fp32_follows_oracle_training():
         ref = O.clm_loss(O.decoder_forward(full, c, ids, None, "rope", None).logits, labels)
         ref.backward()
         opt.step()
+        tr16.train_step(lambda: m16.clm_loss(ids.to(DEV), labels.to(DEV)))
         print(f"step {step}: HIP fp32 loss {loss.item():.7f}  oracle loss {ref.item():.7f}")
         assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item())), (step, loss.item(), ref.item())
     for name in ("all_layer.1.feed_forward.out.weight", "all_layer.0.attention.query.weight", "lm_head.dense.weight",

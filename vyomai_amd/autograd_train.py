@@ -40,7 +40,7 @@ class _WtRegistry:
 
     def __init__(self) -> None:
         self.entries = []      # [weakref(owner), key_fn, src_fn, dst_view, last_used_epoch]
-        self.batch = None
+        self.batches = {}
         self.epoch_done = -1
 
     def register(self, owner, key_fn, src_fn, dst):
@@ -59,10 +59,14 @@ class _WtRegistry:
         if not live:
             return
         pairs = [(e[2](e[0]()), e[3]) for e in live]
-        keys = [(s_.data_ptr(), d_.data_ptr()) for s_, d_ in pairs]
-        if self.batch is None or self.batch.keys != keys:
-            self.batch = ops.TransposeBatch(pairs)
-        self.batch.run()
+        # one launch per dtype (a bf16 model and an fp32 one trained in the same process share this registry)
+        for dt in sorted({s_.dtype for s_, _ in pairs}, key=str):
+            sub = [(s_, d_) for s_, d_ in pairs if s_.dtype == dt]
+            keys = [(s_.data_ptr(), d_.data_ptr()) for s_, d_ in sub]
+            batch = self.batches.get(dt)
+            if batch is None or batch.keys != keys:
+                batch = self.batches[dt] = ops.TransposeBatch(sub)
+            batch.run()
         for e in live:
             e[0]()._vy_wt_key = e[1](e[0]())
 
