@@ -407,6 +407,16 @@ int main() {
   (void)hipMalloc(&dclk, 8192 * 8); (void)hipMalloc(&dsink, 64);
   (void)hipMemcpy((void*)dX, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
   (void)hipMemcpy((void*)dW, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+  if (getenv("INGEST")) {   // which path takes a stage in faster: LDS-DMA or plain loads into registers?
+    for (int rep = 0; rep < 2; ++rep) {
+      run<1, 0, 192>("LDS-DMA loads only (issue, wait, barrier)");
+      run<1, 4, 192>("loads only, global_load_dwordx4 into registers (no LDS write)");
+      run<1, 5, 192>("loads only, register path + ds_write_b128");
+      run<5, 0, 192>("MFMA + LDS-DMA loads");
+      run<5, 4, 192>("MFMA + register loads (no LDS write)");
+    }
+    return 0;
+  }
   if (getenv("QUICK")) {
     for (int rep = 0; rep < 2; ++rep) {
       run<4, 0, 192>("32x32x16: MFMA only");
