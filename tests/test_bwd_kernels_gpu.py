@@ -120,6 +120,12 @@ BWD_CASES = [
     (2, 4, 2, 150, 150, True, 0, False, 96),
     (1, 2, 1, 65, 65, True, 0, False, 160),
     (1, 2, 2, 64, 64, False, 0, False, 40),
+    # queries behind a cached prefix (L != S, start_pos): tuned and general kernels
+    (2, 12, 4, 40, 100, True, 60, True),
+    (1, 4, 4, 200, 328, True, 128, False),
+    (2, 4, 2, 40, 100, True, 60, True, 128),
+    (1, 4, 1, 70, 200, True, 130, False, 256),
+    (2, 2, 2, 33, 77, False, 0, True, 72),
 ]
 
 
