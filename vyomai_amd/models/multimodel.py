@@ -9,6 +9,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from ..autograd_train import defer_residual_grads as _defer
 from ..layers.attention import DecoderAttention, DecoderAttentionGqa
 from ..layers.ffn import FeedForward
 from ..layers.kv_cache import DynamicCache, StaticCache
@@ -35,6 +36,7 @@ class DecoderLayer(nn.Module):
 
     def forward(self, hidden_state, attention_mask, freqs=None, use_cache: Optional[bool] = False,
                 start_pos: Optional[int] = 0) -> torch.Tensor:
+        _defer(hidden_state)  # training: its residual-path gradients are added in the QKV dgrad epilogue
         out = self.attention(hidden_state=hidden_state, attention_mask=attention_mask, freqs=freqs,
                              use_cache=use_cache, start_pos=start_pos)
         return self.feed_forward(out, hidden_state)

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..autograd_train import defer_residual_grads as _defer
 from ..layers.attention import VisionAttention, _shadow
 from ..layers.ffn import FeedForward
 from ..layers.mask import AttnMask
@@ -31,6 +32,7 @@ class EncoderLayer(nn.Module):
         self.layer_idx = layer_idx
 
     def forward(self, hidden_state, attention_mask, freqs=None) -> torch.Tensor:
+        _defer(hidden_state)  # training: its residual-path gradients are added in the qkv dgrad epilogue
         out = self.attention(hidden_state=hidden_state, attention_mask=attention_mask, freqs=freqs)
         return self.feed_forward(out, hidden_state)
 
