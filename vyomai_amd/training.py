@@ -148,6 +148,9 @@ class BucketReducer:
         self.arena = arena
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # rehearsal knob: issue the bucket collectives even in a one-rank group (the RCCL calls, their stream
+        # semantics and the per-bucket optimizer behind them run on a one-GPU box exactly as they do at N > 1)
+        self.force = dist.is_initialized() and os.environ.get("VY_DDP_FORCE_COLLECTIVES") == "1"
         self.average = average
         self.comm_dtype = comm_dtype
         self.enabled = True   # False during the non-final micro-steps of gradient accumulation
@@ -221,7 +224,7 @@ class BucketReducer:
         self._launched[b] = True
         self.launch_order.append(b)
         work = None
-        if self.world > 1:
+        if self.world > 1 or self.force:
             s, e = self.buckets[b]
             view = self.arena.grad[s:e]
             if self.comm_dtype is not None:
@@ -238,7 +241,7 @@ class BucketReducer:
     def writeback(self, b: int) -> None:
         """comm_dtype buckets: the reduced low-precision sum back into the fp32 arena (the caller has
         made the current stream wait for the bucket's all-reduce)."""
-        if self.comm_dtype is not None and self.world > 1 and b in self._comm:
+        if self.comm_dtype is not None and (self.world > 1 or self.force) and b in self._comm:
             s, e = self.buckets[b]
             _convert(self._comm[b], self.arena.grad[s:e])
 
