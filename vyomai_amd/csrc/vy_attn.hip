@@ -923,3 +923,11 @@ int vy_attn_decode_ex(const void* q, int64_t q_sb, int64_t q_sh, const void* k, 
   if (dtype == VY_BF16) return launch_rowwise<bf16>(p, dh, st, who);
   return launch_rowwise<float>(p, dh, st, who);
 }
+
+// diagnostics: how many workgroups of the tuned forward kernel the runtime places on one CU (registers, LDS)
+extern "C" int vy_debug_attn_occupancy(int dh) {
+  int n = -1;
+  hipError_t e = dh == 64 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<64>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_mfma_kernel<128>, 256, 0);
+  return e == hipSuccess ? n : -1;
+}
