@@ -37,10 +37,13 @@ struct DecDbg { unsigned long long* buf; int slot; int max_wg; };
     }                                                                                                         \
   }
 
-// 16 bytes of a stream that exactly one workgroup reads exactly once per step (a weight tile, a K/V row): the
-// non-temporal policy (`global_load_dwordx4 ... nt`) -- MI355X_MICROARCH.md "nt-weights": issued -> landed 18-19 % shorter
-// for once-read decode streams; never on data other CUs re-read (the activations keep the default policy)
-__device__ __forceinline__ bf16x8 dec_load_once(const bf16* p) {
+// 16 bytes of a stream too large to stay on chip until it is read again: the non-temporal policy
+// (`global_load_dwordx4 ... nt`).  Used for the K/V rows of a LARGE cache only (dec_attn_kernel<..., NT>): at B = 32 the
+// caches are 680 MB per step, and streamed with the default policy they push the 170 MB of weights out of the
+// Infinity Cache every step (step 514.5 -> 501 us with nt); a small cache (configs[4]: 5.5 MB) is served on chip from one
+// step to the next and must keep the default policy (+5 % per token with nt).  The weight tiles keep the default policy
+// (nt on them alone: +1 %).
+__device__ __forceinline__ bf16x8 dec_load_stream(const bf16* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
 }
 
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void dec_gemm16_kernel(const DecGemmArgs p, co
   bf16x8 a[U], b0[U], b1[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    a[u] = dec_load_once(wp + 128 * u);
+    a[u] = *reinterpret_cast<const bf16x8*>(wp + 128 * u);
     b0[u] = *reinterpret_cast<const bf16x8*>(xp0 + 128 * u);
     b1[u] = *reinterpret_cast<const bf16x8*>(xp1 + 128 * u);
   }
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void dec_gemm64p_kernel(const DecGemmArgs p, c
   bf16x8 a[U], b0[U], b1[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    a[u] = dec_load_once(wp + 32 * u);
+    a[u] = *reinterpret_cast<const bf16x8*>(wp + 32 * u);
     b0[u] = *reinterpret_cast<const bf16x8*>(xp0 + 32 * u);
     b1[u] = *reinterpret_cast<const bf16x8*>(xp1 + 32 * u);
   }
@@ -483,7 +486,7 @@ __device__ __forceinline__ float dec_stride_sum(float v) {
   return __builtin_bit_cast(float, (unsigned)s32[0]) + __builtin_bit_cast(float, (unsigned)s32[1]);
 }
 
-template <int DH, int NW, int NP>
+template <int DH, int NW, int NP, bool NT>
 __global__ __launch_bounds__(64 * NW) void dec_attn_kernel(const DecAttnArgs p) {
   constexpr int LPK = DH / 8, KPW = 64 / LPK, KPP = NW * KPW;
   __shared__ float red_m[NW], red_l[NW];
@@ -502,8 +505,8 @@ __global__ __launch_bounds__(64 * NW) void dec_attn_kernel(const DecAttnArgs p) 
   for (int i = 0; i < NP; ++i) {
     const int j = i * KPP + wave * KPW + g;
     const long long jo = (long long)(j < S ? j : S - 1) * p.c_sl;
-    kr[i] = dec_load_once(kb + jo);
-    vr[i] = dec_load_once(vb + jo);
+    if constexpr (NT) { kr[i] = dec_load_stream(kb + jo); vr[i] = dec_load_stream(vb + jo); }
+    else { kr[i] = *reinterpret_cast<const bf16x8*>(kb + jo); vr[i] = *reinterpret_cast<const bf16x8*>(vb + jo); }
   }
   float qf[8];
 #pragma unroll
@@ -556,16 +559,16 @@ __global__ __launch_bounds__(64 * NW) void dec_attn_kernel(const DecAttnArgs p) 
   }
 }
 
-template <int DH, int NW>
+template <int DH, int NW, bool NT>
 int dec_attn_go(const DecAttnArgs& a, int B, int Smax, hipStream_t st) {
   constexpr int KPP = NW * (64 / (DH / 8));
   const dim3 grid((unsigned)a.h, (unsigned)B), block(64 * NW);
   const int np = (Smax + KPP - 1) / KPP;
-  if (np <= 3) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 3>), grid, block, 0, st, a);
-  else if (np <= 5) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 5>), grid, block, 0, st, a);
-  else if (np <= 7) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 7>), grid, block, 0, st, a);
-  else if (np <= 10) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 10>), grid, block, 0, st, a);
-  else if (np <= 12) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 12>), grid, block, 0, st, a);
+  if (np <= 3) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 3, NT>), grid, block, 0, st, a);
+  else if (np <= 5) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 5, NT>), grid, block, 0, st, a);
+  else if (np <= 7) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 7, NT>), grid, block, 0, st, a);
+  else if (np <= 10) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 10, NT>), grid, block, 0, st, a);
+  else if (np <= 12) hipLaunchKernelGGL((dec_attn_kernel<DH, NW, 12, NT>), grid, block, 0, st, a);
   else return 1;
   return 0;
 }
@@ -832,9 +835,17 @@ int vy_dec_attn(const void* q, int64_t q_sb, const void* k, const void* v, int64
   a.q = (const bf16*)q; a.q_sb = q_sb; a.k = (const bf16*)k; a.v = (const bf16*)v; a.c_sb = c_sb; a.c_sh = c_sh; a.c_sl = c_sl;
   a.out = (bf16*)out; a.o_sb = o_sb; a.pos_dev = pos_dev; a.S = (int)S; a.h = h; a.hk = hk; a.scale = scale;
   const int bound = (int)(pos_dev ? smax : S);
+  // K/V policy (see dec_load_stream): streamed (nt) unless one layer's rows are under 1 MB.  Measured on the 12-layer
+  // d = 768 decoder, whose 170 MB of weights can stay in the Infinity Cache if the K/V stream does not push them out: nt is
+  // ahead at every batch (B = 1 / 2 / 4 / 8 / 32: 349 / 360 / 380 / 368 / 485 us against 355 / 363 / 388 / 399 / 515); on
+  // configs[4] (0.3 MB per layer, 5.8 GB of weights streaming through anyway) the default policy is 5 % ahead.
+  // VY_DEC_ATTN_NT = 0 / 1 forces it
+  static const int nt_env = [] { const char* e = getenv("VY_DEC_ATTN_NT"); return e ? atoi(e) : -1; }();
+  const int64_t layer_bytes = 2ll * B * hk * (pos_dev ? smax : S) * dh * 2;
+  const bool nt = nt_env < 0 ? layer_bytes > (1ll << 20) : nt_env != 0;
   int rc;
-  if (dh == 64) rc = dec_attn_go<64, 8>(a, B, bound, st);
-  else rc = dec_attn_go<256, 16>(a, B, bound, st);
+  if (dh == 64) rc = nt ? dec_attn_go<64, 8, true>(a, B, bound, st) : dec_attn_go<64, 8, false>(a, B, bound, st);
+  else rc = nt ? dec_attn_go<256, 16, true>(a, B, bound, st) : dec_attn_go<256, 16, false>(a, B, bound, st);
   if (rc) return VY_ERR_UNSUPPORTED;
   VY_CHECK_LAUNCH("vy_dec_attn");
   return VY_OK;
