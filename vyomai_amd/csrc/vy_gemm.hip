@@ -709,8 +709,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
       if (PW % NW == 0 || wave + NW * t < PW) {
         const bf16* s = wsrc[t] + k0;
         if (ktail && k0 + wk[t] >= K) s = zero;
+        // one row tile (the 32-row decode launches: the vocabulary projection, 77 MB): every weight tile is read by one
+        // workgroup once per step -- streamed (aux 2 = nt) so that it does not push the layer weights out of the
+        // Infinity Cache (see dec_load_stream, vy_decode.hip)
+        constexpr int W_AUX = BM == 32 ? 2 : 0;
         __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
-                                         (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
+                                         (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, W_AUX);
       }
     }
   };
