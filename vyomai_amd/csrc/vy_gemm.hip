@@ -439,7 +439,9 @@ __device__ __forceinline__ void gemm_epilogue(typename AccTile<BM, BN, WGM, WGN,
               }
             }
             if (ep.vec_ok && n + 8 <= N) {
-              *reinterpret_cast<bf16x8*>(ep.pre + m * ep.ldy + n) = d8;
+              // read again only by the backward pass, milliseconds later: streamed, so that it does not take the place of
+              // the activation written beside it (FFN2's operand) in the Infinity Cache
+              __builtin_nontemporal_store(d8, reinterpret_cast<bf16x8*>(ep.pre + m * ep.ldy + n));
             } else {
               for (int e = 0; e < 8 && n + e < N; ++e) ep.pre[m * ep.ldy + n + e] = d8[e];
             }
