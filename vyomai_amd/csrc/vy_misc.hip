@@ -467,10 +467,13 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
   for (; i < n; i += stride) {
     if (i + 3 < n) {
-      f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
-      f32x4 mv = *reinterpret_cast<f32x4*>(m + i);
-      f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+      // the optimizer state is touched once per step (3.7 GB per step for 124 M parameters, under the backward pass on a side
+      // stream): streamed both ways (nt), so that it does not take the Infinity Cache away from the backward kernels'
+      // hand-offs.  The bf16 working copy keeps the default policy: the next forward reads it.
+      f32x4 pv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + i));
+      const f32x4 gv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
+      f32x4 mv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + i));
+      f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + i));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float gg = gv[e] * gscale;
@@ -480,9 +483,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
         const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
         pv[e] -= (lr / bc1) * (mv[e] / denom);
       }
-      *reinterpret_cast<f32x4*>(p + i) = pv;
-      *reinterpret_cast<f32x4*>(m + i) = mv;
-      *reinterpret_cast<f32x4*>(v + i) = vv;
+      __builtin_nontemporal_store(pv, reinterpret_cast<f32x4*>(p + i));
+      __builtin_nontemporal_store(mv, reinterpret_cast<f32x4*>(m + i));
+      __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + i));
       if (pb) {
         bf16x4 o;
 #pragma unroll
