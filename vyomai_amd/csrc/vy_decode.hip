@@ -605,9 +605,8 @@ __global__ __launch_bounds__(256) void dec_gemv1_kernel(const DecGemvArgs p) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       const int off = (b * CH + u) * 512;
-      // (default policy: with `nt` this HBM-bound stream -- 5 GB per token -- measured 1.8 % slower)
-      wa[buf][u] = *reinterpret_cast<const bf16x8*>(wp + off);
-      if constexpr (EPI == GV_GATED) wb[buf][u] = *reinterpret_cast<const bf16x8*>(wp2 + off);
+      wa[buf][u] = dec_load_stream(wp + off);   // 5.8 GB of weights per token, each byte once: streamed
+      if constexpr (EPI == GV_GATED) wb[buf][u] = dec_load_stream(wp2 + off);
       xa[buf][u] = *reinterpret_cast<const bf16x8*>(xp + off);
     }
   };
