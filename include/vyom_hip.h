@@ -217,6 +217,25 @@ int vy_attn_bwd(const void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl,
                 int64_t B, int h, int hk, int64_t L, int64_t S, int dh, float scale, int dtype,
                 void* stream);
 
+/* ---- data-parallel gradient exchange (RCCL) --------------------------------------------------------------------
+ * Replaces what the reference gets from accelerate / torch DDP (Examples/vyom-ai-decoder_clm.ipynb cell 31,
+ * Examples/vyom-ai-accelerate-multimodel-2t4.ipynb cells 1-2): one process per GPU, one communicator per process.
+ *   vy_ddp_unique_id   rank 0 fills 128 bytes; the host hands them to every rank (any side channel: torch.distributed's
+ *                      store, MPI, a file)
+ *   vy_ddp_init        collective; binds the communicator to the calling thread's current HIP device
+ *   vy_ddp_all_reduce_async  in-place SUM of `count` elements (VY_F32 | VY_BF16) enqueued on `stream`: the caller orders
+ *                      it behind the kernels that wrote the bucket and ahead of its consumers with events / stream waits
+ *                      (there is no separate wait call: completion is stream order)
+ * RCCL is bound at run time (the copy already in the process, e.g. torch's, else librccl.so): where it is absent these
+ * return VY_ERR_UNSUPPORTED.  The number of CUs RCCL's channel kernels occupy beside the backward GEMMs is RCCL's own
+ * knob (NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS in the environment of the process), read at vy_ddp_init. */
+int vy_ddp_unique_id(void* id128);
+int vy_ddp_init(const void* id128, int rank, int world);
+int vy_ddp_world(void);   /* 0 before vy_ddp_init */
+int vy_ddp_rank(void);    /* -1 before vy_ddp_init */
+int vy_ddp_all_reduce_async(void* buf, int64_t count, int dtype, void* stream);
+int vy_ddp_destroy(void);
+
 /* Fused AdamW over a flat fp32 parameter arena; also refreshes the bf16 working copy.
  * p, m, v fp32 [n]; g fp32 [n]; p_bf16 (nullable) bf16 [n].  Matches torch.optim.AdamW. */
 int vy_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,

@@ -35,6 +35,14 @@ def test_argument_errors_are_reported_without_a_gpu():
         buf = (ctypes.c_char * 4096)()
         p = (ctypes.addressof(buf) + 15) // 16 * 16
         _lib.call("vy_linear_fwd", p, 12, p, 12, None, None, 0, p, 16, None, 4, 8, 12, 0, 1, None)
+    # the data-parallel surface: nothing but argument checks can run here (no GPU, no communicator)
+    lib = _lib.load()
+    assert lib.vy_ddp_world() == 0 and lib.vy_ddp_rank() == -1
+    with pytest.raises(_lib.VyomHipError, match="no communicator|RCCL is not available"):
+        _lib.call("vy_ddp_all_reduce_async", p, 16, 0, None)
+    with pytest.raises(_lib.VyomHipError, match="bad arguments|RCCL is not available"):
+        _lib.call("vy_ddp_init", p, 3, 2)
+    _lib.call("vy_ddp_destroy")
 
 
 def test_no_cpu_fallback():

@@ -16,6 +16,6 @@ objs=""
 for o in $root/vyomai_amd/lib/*.o; do
   [ "$(basename $o)" = "${f%.hip}.o" ] || objs="$objs $o"
 done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $root/vyomai_amd/lib/libvyom_hip_ab.so $objs $tmp/ab.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o $root/vyomai_amd/lib/libvyom_hip_ab.so $objs $tmp/ab.o -ldl
 rm -rf $tmp
 echo built $root/vyomai_amd/lib/libvyom_hip_ab.so

@@ -46,4 +46,12 @@ print(f"bf16 buckets over RCCL: loss {loss16:.6f}; max |param diff| {d16.max().i
 assert d16.mean().item() < 2e-4 and abs(loss16 - loss_ref) < 2e-2
 dist.barrier()
 dist.destroy_process_group()
+# the library's own communicator (vy_ddp_*: ncclGetUniqueId / ncclCommInitRank / ncclAllReduce on a stream it is handed),
+# no torch.distributed group at all
+gotn, lossn, trn = train(native_rccl=True)
+assert trn.native is not None and trn.reducer.native is trn.native and trn.native.world == 1
+dn = (gotn - ref).abs()
+print(f"fp32 buckets over the native communicator: loss {lossn:.6f}; max |param diff| {dn.max().item():.3e} mean {dn.mean().item():.3e}")
+assert dn.mean().item() <= 3 * noise + 1e-6 and abs(lossn - loss_ref) < 1e-3
+trn.native.close()
 print("ok")

@@ -60,9 +60,13 @@ PROTOTYPES = {
     "vy_decoder_step": [_p, _p, _i64, _p, _p, _p, _i64, _p],
     "vy_gemma_decoder_step": [_p, _p, _i64, _p, _i64, _p],
     "vy_cast": [_p, _p, _i64, _i, _i, _p],
+    "vy_ddp_unique_id": [_p],
+    "vy_ddp_init": [_p, _i, _i],
+    "vy_ddp_all_reduce_async": [_p, _i64, _i, _p],
+    "vy_ddp_destroy": [],
 }
 OTHER_SYMBOLS = ["vy_last_error", "vy_abi_version", "vy_layernorm_bwd_ws_rows", "vy_decode_ws_bytes",
-                 "vy_gemma_ws_bytes"]
+                 "vy_gemma_ws_bytes", "vy_ddp_world", "vy_ddp_rank"]
 ALL_SYMBOLS = list(PROTOTYPES) + OTHER_SYMBOLS
 
 

@@ -135,6 +135,57 @@ class FlatArena:
         self.grad.zero_()
 
 
+class _StreamWork:
+    """What torch.distributed's Work is to the reducer: wait() makes the CURRENT stream wait for the collective."""
+
+    def __init__(self, event: torch.cuda.Event) -> None:
+        self.event = event
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class NativeComm:
+    """The library's own RCCL communicator (vy_ddp_*, include/vyom_hip.h) behind the reducer instead of
+    torch.distributed.all_reduce: one communicator per process on the current device, the bucket all-reduce enqueued on
+    a dedicated HIP stream that first waits for the compute stream.  torch.distributed (any backend) is used once, to hand
+    rank 0's 128-byte id to the other ranks.  Opt-in: FlatTrainer(native_rccl=True) or VY_DDP_NATIVE=1."""
+
+    def __init__(self, device: torch.device, process_group=None) -> None:
+        from . import _lib
+        self._lib = _lib
+        # the RCCL that ships with torch is already mapped into this process (libtorch_hip links it): make ITS symbols the
+        # ones vy_ddp_* binds to (dlsym on the global scope), rather than mapping a second copy from /opt/rocm
+        import ctypes
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            _lib.call("vy_ddp_unique_id", uid.data_ptr())
+        if world > 1:
+            backend = dist.get_backend(process_group)
+            t = uid.to(device) if backend == "nccl" else uid
+            dist.broadcast(t, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                           group=process_group)
+            uid = t.cpu()
+        torch.cuda.set_device(device)
+        _lib.call("vy_ddp_init", uid.data_ptr(), rank, world)
+        self.world, self.rank = world, rank
+        self.stream = torch.cuda.Stream(device=device)
+
+    def all_reduce(self, view: torch.Tensor) -> _StreamWork:
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self._lib.call("vy_ddp_all_reduce_async", view.data_ptr(), view.numel(), self._lib.dtype_code(view.dtype),
+                       self.stream.cuda_stream)
+        return _StreamWork(self.stream.record_event())
+
+    def close(self) -> None:
+        self._lib.call("vy_ddp_destroy")
+
+
 class BucketReducer:
     """Bucketed, overlapped gradient all-reduce over a flat gradient arena.
 
@@ -144,13 +195,14 @@ class BucketReducer:
     exchange."""
 
     def __init__(self, arena: FlatArena, process_group=None, bucket_bytes: int = 64 << 20,
-                 average: bool = True, comm_dtype: Optional[torch.dtype] = None):
+                 average: bool = True, comm_dtype: Optional[torch.dtype] = None, native: Optional[NativeComm] = None):
         self.arena = arena
         self.pg = process_group
+        self.native = native   # the library's own RCCL communicator instead of torch.distributed.all_reduce
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # rehearsal knob: issue the bucket collectives even in a one-rank group (the RCCL calls, their stream
         # semantics and the per-bucket optimizer behind them run on a one-GPU box exactly as they do at N > 1)
-        self.force = dist.is_initialized() and os.environ.get("VY_DDP_FORCE_COLLECTIVES") == "1"
+        self.force = (dist.is_initialized() or native is not None) and os.environ.get("VY_DDP_FORCE_COLLECTIVES") == "1"
         self.average = average
         self.comm_dtype = comm_dtype
         self.enabled = True   # False during the non-final micro-steps of gradient accumulation
@@ -233,7 +285,10 @@ class BucketReducer:
                     buf = self._comm[b] = torch.empty(e - s, dtype=self.comm_dtype, device=view.device)
                 _convert(view, buf)
                 view = buf
-            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if self.native is not None:
+                work = self.native.all_reduce(view)
+            else:
+                work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._works.append((b, work))
         if self.on_bucket is not None:
             self.on_bucket(b, work)
@@ -288,7 +343,7 @@ class FlatTrainer:
                  eps: float = 1e-8, weight_decay: float = 0.01, compute_dtype: torch.dtype = torch.bfloat16,
                  process_group=None, bucket_bytes: int = 64 << 20, overlap_optimizer: bool = True,
                  accumulate_steps: int = 1, max_grad_norm: Optional[float] = None,
-                 grad_comm_dtype: Optional[torch.dtype] = None):
+                 grad_comm_dtype: Optional[torch.dtype] = None, native_rccl: Optional[bool] = None):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         for m in model.modules():
@@ -298,7 +353,14 @@ class FlatTrainer:
         self.arena = FlatArena(model, shadow_dtype=None if compute_dtype == torch.float32 else compute_dtype)
         self.m = torch.zeros_like(self.arena.master)
         self.v = torch.zeros_like(self.arena.master)
-        self.reducer = BucketReducer(self.arena, process_group, bucket_bytes, comm_dtype=grad_comm_dtype)
+        # native_rccl: the exchange goes through the library's own RCCL communicator (vy_ddp_*) instead of
+        # torch.distributed.all_reduce (None: the VY_DDP_NATIVE environment variable decides; default off)
+        if native_rccl is None:
+            native_rccl = os.environ.get("VY_DDP_NATIVE") == "1"
+        self.native = None
+        if native_rccl and self.arena.master.is_cuda and (dist.is_initialized() or os.environ.get("VY_DDP_FORCE_COLLECTIVES") == "1"):
+            self.native = NativeComm(self.arena.master.device, process_group)
+        self.reducer = BucketReducer(self.arena, process_group, bucket_bytes, comm_dtype=grad_comm_dtype, native=self.native)
         self.step_count = 0
         self.accumulate_steps = max(1, int(accumulate_steps))
         self.max_grad_norm = max_grad_norm
