@@ -371,9 +371,30 @@ def main():
         # the training model is released first; a failure here leaves a note, not a broken bench line.
         # configs[3] (caption training, "B=64 on 1->8 GPUs") runs on every rank under the same process group;
         # configs[4] (single-sequence decode) on one GPU only.
+        others = {}
+        if world == 1:
+            # SURVEY section 8d's second run: the same step with 25 % right padding (key-padding path of the attention
+            # kernels, ignored label positions) -- a few steps on the trainer that is still alive
+            try:
+                am = torch.ones(B, L, dtype=torch.long, device=dev)
+                am[:, L - L // 4:] = 0
+                lab = ids.clone()
+                lab[am == 0] = -100
+                for _ in range(2):
+                    trainer.train_step(lambda: model.clm_loss(ids, lab, am))
+                torch.cuda.synchronize()
+                t0p = time.perf_counter()
+                for _ in range(3):
+                    lp = trainer.train_step(lambda: model.clm_loss(ids, lab, am))
+                torch.cuda.synchronize()
+                dtp = (time.perf_counter() - t0p) / 3
+                others["configs[1] with 25 % right padding"] = {
+                    "workload": "the headline step with attention_mask: the last 128 of 512 positions padded (key-padding + causal mask, labels -100 there)",
+                    "ms_per_step": round(dtp * 1e3, 3), "tokens_per_sec_incl_padding": round(B * L / dtp, 1), "loss": round(float(lp.item()), 4)}
+            except Exception as ex:   # noqa: BLE001
+                others["configs[1] with 25 % right padding"] = {"error": f"{type(ex).__name__}: {ex}"}
         del trainer, model
         torch.cuda.empty_cache()
-        others = {}
         todo = [("configs[3]", "tools.bench_vlm_training")]
         if world == 1:
             todo.append(("configs[4]", "tools.bench_paligemma"))
