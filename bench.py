@@ -276,7 +276,12 @@ def main():
     elif a.force_dist:
         os.environ["VY_DDP_FORCE_COLLECTIVES"] = "1"
         kw = {"device_id": dev} if a.backend == "nccl" else {}
-        dist.init_process_group(a.backend, init_method="tcp://127.0.0.1:29517", rank=0, world_size=1, **kw)
+        import socket
+        so = socket.socket()
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+        so.close()
+        dist.init_process_group(a.backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
 
     import vyomai_amd as V
     from vyomai_amd import recipe

@@ -33,7 +33,9 @@ ref, loss_ref, _ = train()
 ref2, _, _ = train()
 noise = (ref2 - ref).abs().mean().item()
 os.environ["VY_DDP_FORCE_COLLECTIVES"] = "1"
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+import socket
+_s = socket.socket(); _s.bind(("127.0.0.1", 0)); _port = _s.getsockname()[1]; _s.close()
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_port}", rank=0, world_size=1, device_id=dev)
 got, loss_got, tr = train()
 assert tr.reducer.force and len(tr.reducer.launch_order) == len(tr.reducer.buckets) > 1
 d = (got - ref).abs()
