@@ -2425,8 +2425,9 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = k0 + u * 512;
-      wv[u] = *reinterpret_cast<const bf16x8*>(w + (kk < K ? kk : 0));
-      if constexpr (GATED) wv2[u] = *reinterpret_cast<const bf16x8*>(w2 + (kk < K ? kk : 0));
+      // (each weight byte once per step: streamed -- MI355X_MICROARCH.md nt-weights; see dec_load_stream, vy_decode.hip)
+      wv[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w + (kk < K ? kk : 0)));
+      if constexpr (GATED) wv2[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2 + (kk < K ? kk : 0)));
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
