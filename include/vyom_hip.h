@@ -241,6 +241,13 @@ int vy_ddp_destroy(void);
 int vy_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int64_t step,
                   float grad_scale, const float* grad_scale_dev, void* stream);
+/* The same with a gate (nullable): one fp32 on the device; when it reads 0 the launch changes nothing.  Data-parallel
+ * training with parameters that some ranks' batches do not reach (the reference's multimodal model under
+ * find_unused_parameters=True, Examples/vyom-ai-accelerate-multimodel-2t4.ipynb cell 1): whether such a parameter is
+ * updated is decided by a flag all-reduced over the ranks, read here on the device. */
+int vy_adamw_step_gated(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                        float grad_scale, const float* grad_scale_dev, const float* gate, void* stream);
 /* grad_scale_dev (nullable): one fp32 on the device multiplied into grad_scale by the kernel -- the
  * clip_grad_norm_ coefficient min(1, max_norm / (norm + 1e-6)) of the reference's training loops
  * (Examples/vyomai-fused-kernals-2t4.ipynb cell 0) without a host round trip. */

@@ -37,7 +37,9 @@ class Tiny(nn.Module):
 
 def _torch_adamw(tr):
     """Stand-in for the vy_adamw_step launch (GPU only): torch.optim.AdamW's arithmetic on an arena range."""
-    def step(lo, hi, step_no, scale_dev=None):
+    def step(lo, hi, step_no, scale_dev=None, gate=None):
+        if gate is not None and float(gate) == 0.0:
+            return
         a = tr.arena
         g = a.grad[lo:hi] * tr._scale
         if scale_dev is not None:
@@ -177,6 +179,92 @@ def test_accumulate_2_world_2_equals_one_rank_on_the_concatenated_batch(comm):
     finally:
         os.environ.pop("VY_TEST_COMM", None)
     assert q.get(timeout=5) == "ok"
+
+
+class Branchy(nn.Module):
+    """`side` is used only when the batch asks for it -- e.g. a vision tower that a text-only batch skips."""
+    def __init__(self):
+        super().__init__()
+        self.nobody = nn.Linear(8, 8)   # used by no rank at all
+        self.a = nn.Linear(16, 32)
+        self.side = nn.Linear(16, 32)
+        self.b = nn.Linear(32, 8)
+
+    def forward(self, x, use_side):
+        h = torch.tanh(self.a(x))
+        if use_side:
+            h = h + self.side(x)
+        return self.b(h)
+
+
+def _unused_on_one_rank_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = Branchy()
+    ref = Branchy()
+    ref.load_state_dict(model.state_dict())
+    nobody0 = model.nobody.weight.detach().clone()
+    tr = _make_trainer(model, bucket_bytes=1024)
+    assert len(tr.reducer.buckets) >= 3
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(3, world, 5, 16, generator=g)
+    opt = torch.optim.AdamW([p for n, p in ref.named_parameters() if not n.startswith("nobody")], lr=1e-2, weight_decay=0.1)
+    for step in range(3):
+        # rank 1's batch never reaches `side`; rank 0's does
+        tr.train_step(lambda: model(data[step, rank], use_side=(rank == 0)).pow(2).mean())
+        # every rank issued its collectives in bucket order although they became ready in different orders
+        assert tr.reducer.launch_order == list(range(len(tr.reducer.buckets))), tr.reducer.launch_order
+        # what torch DDP (find_unused_parameters=True) computes: the mean over ranks, a rank without the branch counting 0
+        opt.zero_grad()
+        loss = sum(ref(data[step, r], use_side=(r == 0)).pow(2).mean() for r in range(world)) / world
+        loss.backward()
+        opt.step()
+    # the replicas stay bit-identical: gather rank 1's masters on rank 0
+    mine = tr.arena.master.clone()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    assert torch.equal(both[0], both[1]), "the ranks' parameters diverged"
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p, q, atol=1e-6), (n, (p - q).abs().max())
+    assert torch.equal(model.nobody.weight, nobody0), "a parameter no rank touched was updated (weight decay)"
+    # a second backward before optimizer_step() would add local gradients on top of a reduced sum: refused
+    tr.zero_grad()
+    tr.backward(model(data[0, rank], True).pow(2).mean())
+    with pytest.raises(RuntimeError, match="accumulate_steps"):
+        tr.backward(model(data[0, rank], True).pow(2).mean())
+    if rank == 0:
+        out.put("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_parameter_unused_on_one_rank_keeps_the_replicas_identical():
+    """the touched set was rank-local, so a parameter one rank's batch skipped was updated on the other
+    ranks only; and buckets went out in readiness order, which differs between such ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unused_on_one_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == "ok"
+
+
+def test_second_backward_without_accumulate_steps_is_allowed_only_where_it_is_harmless():
+    """One rank, no overlapped optimizer, no collectives: the gradients simply add up (plain torch semantics)."""
+    torch.manual_seed(0)
+    model = Tiny()
+    tr = _make_trainer(model)
+    x = torch.randn(4, 16)
+    tr.zero_grad()
+    tr.backward(model(x).pow(2).mean())
+    g1 = tr.arena.grad.clone()
+    tr.backward(model(x).pow(2).mean())
+    assert torch.allclose(tr.arena.grad, 2 * g1, atol=1e-6)
 
 
 # ---- compute-dtype copies of the weights (layers.attention._shadow / _packed_shadow) -------------

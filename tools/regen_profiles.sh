@@ -12,9 +12,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/roofline -o rp -- python3 $ROOT/tools/roofline_probe.py > $OUT/roofline.log 2>&1
 echo "roofline probe traced"
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python3 $ROOT/tools/roofline_probe.py > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 $ROOT/tools/roofline_probe.py > /dev/null 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_hit -o p -- python3 $ROOT/tools/roofline_probe.py > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p -- python3 $ROOT/tools/roofline_probe.py > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o p -- python3 $ROOT/tools/roofline_probe.py > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_hit -o p -- python3 $ROOT/tools/roofline_probe.py > $OUT/pmc_hit.log 2>&1
 echo "pmc passes done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/decode -o dec -- python3 $ROOT/tools/bench_decode_step.py --iters 20 > $OUT/decode.log 2>&1
 echo "decode step traced"

@@ -44,6 +44,7 @@ PROTOTYPES = {
                     _p, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p, _i64, _i64, _i64,
                     _i, _i64, _p, _i64, _p, _p, _i64, _i64, _i, _i, _i64, _i64, _i, _f, _i, _p],
     "vy_adamw_step": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p, _p],
+    "vy_adamw_step_gated": [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p, _p, _p],
     "vy_sumsq": [_p, _i64, _p, _p, _p],
     "vy_linear_dropout_fwd": [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _f, _u64, _u64, _i, _p],
     "vy_dropout": [_p, _i64, _p, _i64, _i64, _i64, _f, _u64, _u64, _i, _p],

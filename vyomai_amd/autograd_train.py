@@ -615,7 +615,9 @@ class LMHeadLossFn(torch.autograd.Function):
         if fused:
             # one pass: loss AND the unit gradient (d loss / d logits for an upstream gradient of 1),
             # written over the logits; backward scales by the actual upstream gradient (linearity)
-            acc[1] = (shifted != ignore_index).sum()
+            # (rows with an out-of-range label contribute neither loss nor gradient -- the kernel raises err_flag for
+            # them -- so they must not count in the mean either, exactly as on the two-pass path)
+            acc[1] = ((shifted != ignore_index) & (shifted >= 0) & (shifted < V)).sum()
             ops.xent_fused_(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2], _one(dev), err_flag)
         else:
             ops.xent_fwd(logits, shifted, ignore_index, lse, acc[0:1], acc[1:2], err_flag)

@@ -461,7 +461,8 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const vy_transpo
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, bf16* __restrict__ pb, int64_t n, float lr, float b1,
                              float b2, float eps, float wd, float bc1, float bc2_sqrt, float gscale,
-                             const float* __restrict__ gscale_dev) {
+                             const float* __restrict__ gscale_dev, const float* __restrict__ gate) {
+  if (gate && *gate == 0.0f) return;       // a parameter no rank had a gradient for: left alone (vy_adamw_step_gated)
   if (gscale_dev) gscale *= *gscale_dev;   // e.g. the gradient-clipping coefficient, computed on the device
   int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
@@ -1025,9 +1026,20 @@ extern "C" int vy_transpose_batched(const vy_transpose_desc* descs_dev, int32_t 
   return VY_OK;
 }
 
+extern "C" int vy_adamw_step_gated(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                   float grad_scale, const float* grad_scale_dev, const float* gate, void* stream);
+
 extern "C" int vy_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int64_t step,
                              float grad_scale, const float* grad_scale_dev, void* stream) {
+  return vy_adamw_step_gated(p, g, m, v, p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                             grad_scale_dev, nullptr, stream);
+}
+
+extern "C" int vy_adamw_step_gated(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                   float grad_scale, const float* grad_scale_dev, const float* gate, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0) VY_FAIL(VY_ERR_ARG, "vy_adamw_step: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const float bc1 = 1.0f - powf(beta1, (float)step);
@@ -1035,7 +1047,7 @@ extern "C" int vy_adamw_step(float* p, const float* g, float* m, float* v, void*
   const int64_t want = vy_cdiv(n, 1024);
   const dim3 grid((unsigned)(want < 8192 ? want : 8192)), block(256);
   hipLaunchKernelGGL(adamw_kernel, grid, block, 0, st, p, g, m, v, (bf16*)p_bf16, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2s, grad_scale, grad_scale_dev);
+                     weight_decay, bc1, bc2s, grad_scale, grad_scale_dev, gate);
   VY_CHECK_LAUNCH("vy_adamw_step");
   return VY_OK;
 }

@@ -213,6 +213,11 @@ extern "C" int vy_gemma_decoder_step(const vy_gemma_plan* p, const void* x, int6
   // (folding the RMSNorm into the products as well -- VY_GEMMA_FUSED=2 -- measured SLOWER, 2.05 vs 1.76 ms per token:
   // every one of the N waves of a product redoes the row statistics and the normalisation of its input)
   const bool fold_norm = fused_env >= 2;
+  // a plan whose weights already carry the norms' (1 + w) can only run on the chain that skips the RMSNorm launches: on
+  // any other chain the factor would be applied twice and the tokens would be wrong without a word
+  if ((p->flags & VY_GEMMA_PRESCALED) && !fused)
+    VY_FAIL(VY_ERR_ARG, "%s: the plan's weights are pre-scaled by the RMSNorm weights, which needs the fused matrix-vector "
+            "chain (bf16, B <= 4, d / ffn / h*dh multiples of 8, VY_GEMMA_FUSED != 0)", who);
   const bool prescaled = fused && (p->flags & VY_GEMMA_PRESCALED);
   static const int rope_env = [] { const char* e = getenv("VY_GEMMA_ROPE_FUSED"); return e ? atoi(e) : 1; }();
   const bool rope_fused = fused && rope_env && p->cos_tab && dh % 4 == 0 && (dh & (dh - 1)) == 0;
@@ -234,6 +239,7 @@ extern "C" int vy_gemma_decoder_step(const vy_gemma_plan* p, const void* x, int6
       }
       rc = vy_dec_gemv1_qkv(qin, L.wqkv, L.bqkv, q, kdst, vdst, L.c_sh, h, hk, dh, rope_fused ? p->cos_tab : nullptr, p->sin_tab,
                             pos, d, prescaled, p->eps, hs);
+      if (rc != VY_OK && rc != VY_ERR_UNSUPPORTED) return rc;   // only an unsupported shape falls through to the general chain
       if (rc == VY_OK) {
         if (p->cos_tab && !rope_fused &&
             (rc = vy_rope_qk(q, (int64_t)h * dh, dh, dh, h, kdst, L.c_sb, L.c_sh, L.c_sl, hk, p->cos_tab, p->sin_tab,
@@ -241,6 +247,7 @@ extern "C" int vy_gemma_decoder_step(const vy_gemma_plan* p, const void* x, int6
         if ((rc = vy_attn_decode_ex(q, (int64_t)h * dh, dh, L.kcache, L.c_sb, L.c_sh, L.c_sl, L.vcache, L.c_sb, L.c_sh, L.c_sl,
                                     ao, (int64_t)h * dh, B, h, hk, pos + 1, nullptr, dh, scale, p->dtype, stream))) return rc;
         if ((rc = vy_dec_gemv1(ao, L.wo, L.bo, cur, x1, d, h * dh, 0, 0.f, hs))) {
+          if (rc != VY_ERR_UNSUPPORTED) return rc;
           if ((rc = vy_gemv_norm(ao, (int64_t)h * dh, L.wo, (int64_t)h * dh, L.bo, nullptr, 0.f, cur, d, x1, d, B, d,
                                  (int64_t)h * dh, stream))) return rc;
         }
@@ -250,10 +257,12 @@ extern "C" int vy_gemma_decoder_step(const vy_gemma_plan* p, const void* x, int6
           gin = n;
         }
         if ((rc = vy_dec_gemv1_gated(gin, L.wgu, act, ffn, d, prescaled, p->eps, hs))) {
+          if (rc != VY_ERR_UNSUPPORTED) return rc;
           if ((rc = vy_gemv_gated(gin, d, L.wgu, d, prescaled ? VY_NORM_PRESCALED : nullptr, p->eps, act, ffn, B, ffn, d,
                                   VY_ACT_GELU_TANH, stream))) return rc;
         }
         if ((rc = vy_dec_gemv1(act, L.wdown, nullptr, x1, nxt, d, ffn, 0, 0.f, hs))) {
+          if (rc != VY_ERR_UNSUPPORTED) return rc;
           if ((rc = vy_gemv_norm(act, ffn, L.wdown, ffn, nullptr, nullptr, 0.f, x1, d, nxt, d, B, d, ffn, stream))) return rc;
         }
         cur = nxt;

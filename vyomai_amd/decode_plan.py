@@ -191,7 +191,11 @@ class GemmaDecodePlan:
         layers = list(model.layers)
         arr = (VyGemmaLayer * len(layers))()
         # single-sequence bf16 decode: RMSNorm folded into the weights (VY_GEMMA_PRESCALE=0: separate RMSNorm launches)
-        prescale = dt == torch.bfloat16 and batch <= 4 and os.environ.get("VY_GEMMA_PRESCALE", "1") != "0"
+        # -- only where the step will run the chain that skips them (the same predicate as vy_gemma_decoder_step's `fused`;
+        # the C side refuses a pre-scaled plan on any other chain)
+        widths_ok = t.hidden_size % 8 == 0 and t.intermediate_size % 8 == 0 and (t.num_attention_heads * t.head_dim) % 8 == 0
+        prescale = (dt == torch.bfloat16 and batch <= 4 and widths_ok and os.environ.get("VY_GEMMA_PRESCALE", "1") != "0"
+                    and os.environ.get("VY_GEMMA_FUSED", "1") != "0")
         for i, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp
             wqkv, bqkv = _packed([a.q_proj, a.k_proj, a.v_proj], layer, "_qkv")

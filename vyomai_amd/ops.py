@@ -291,12 +291,18 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, *, causal: bool, start_po
 
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tensor], lr: float,
                beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
-               grad_scale: float = 1.0, scale_dev: Optional[Tensor] = None) -> None:
-    """scale_dev: optional fp32 device scalar multiplied into grad_scale by the kernel (clip coefficient)."""
-    _need_gpu(p, g, m, v, p_bf16, scale_dev)
+               grad_scale: float = 1.0, scale_dev: Optional[Tensor] = None, gate: Optional[Tensor] = None) -> None:
+    """scale_dev: optional fp32 device scalar multiplied into grad_scale by the kernel (clip coefficient).
+    gate: optional fp32 device scalar; when it is 0 the launch changes nothing (vy_adamw_step_gated)."""
+    _need_gpu(p, g, m, v, p_bf16, scale_dev, gate)
     assert scale_dev is None or (scale_dev.dtype == torch.float32 and scale_dev.numel() == 1)
-    call("vy_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), p.numel(),
-         lr, beta1, beta2, eps, weight_decay, step, grad_scale, _ptr(scale_dev), _stream())
+    if gate is None:
+        call("vy_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), p.numel(),
+             lr, beta1, beta2, eps, weight_decay, step, grad_scale, _ptr(scale_dev), _stream())
+    else:
+        assert gate.dtype == torch.float32 and gate.numel() == 1
+        call("vy_adamw_step_gated", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), p.numel(),
+             lr, beta1, beta2, eps, weight_decay, step, grad_scale, _ptr(scale_dev), gate.data_ptr(), _stream())
 
 
 def sumsq(x: Tensor) -> Tensor:

@@ -249,6 +249,9 @@ class BucketReducer:
     def reset(self) -> None:
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._ready = [False] * len(self.buckets)
+        self._next = 0               # lowest bucket index that has not gone out yet (collective order, see _launch_ready)
+        self.global_flags = None     # after finish() under world > 1: device fp32 [n_params], > 0 where ANY rank had a gradient
         self._works: List = []
         self.launch_order: List[int] = []
         self._seen: set = set()
@@ -270,11 +273,29 @@ class BucketReducer:
         self._seen.add(id(p))
         self._pending[b] += 1
         if self._pending[b] >= self.expect[b]:
-            self._launch(b)
+            self._ready[b] = True
+            self._launch_ready()
 
-    def _launch(self, b: int) -> None:
+    def _launch_ready(self) -> None:
+        """Collectives must be issued in the SAME order on every rank.  A rank whose batch leaves a parameter without a
+        gradient (the reference's multimodal model, find_unused_parameters=True) completes that bucket only at
+        finish(), while the other ranks complete it during backward: so with more than one rank buckets go out
+        strictly by index (0 = the last-registered parameters, which backward reaches first) -- a late bucket holds
+        back the ones behind it on that rank, never reorders them.  One rank alone has no collective to order and
+        hands every bucket to the optimizer the moment it is final."""
+        if self.world > 1 or self.force:
+            while self._next < len(self.buckets) and self._ready[self._next]:
+                self._launch(self._next)
+        else:
+            for b, r in enumerate(self._ready):
+                if r and not self._launched[b]:
+                    self._launch(b)
+
+    def _launch(self, b: int, notify: bool = True):
         self._launched[b] = True
         self.launch_order.append(b)
+        while self._next < len(self.buckets) and self._launched[self._next]:
+            self._next += 1
         work = None
         if self.world > 1 or self.force:
             s, e = self.buckets[b]
@@ -290,8 +311,32 @@ class BucketReducer:
             else:
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._works.append((b, work))
-        if self.on_bucket is not None:
+        if notify and self.on_bucket is not None:
             self.on_bucket(b, work)
+        return work
+
+    def _exchange_flags(self) -> None:
+        """Which parameters received a gradient on ANY rank (one small MAX all-reduce per step, issued by every rank at
+        the same point: after the last bucket).  The all-reduce gives such a parameter the same averaged gradient on
+        every rank, so every rank must update it -- also the ranks whose own batch never reached it; a parameter no
+        rank touched is updated by none (torch DDP leaves globally unused gradients alone as well).  The flags stay on
+        the device: the optimizer launches of locally untouched parameters are gated by them (vy_adamw_step_gated), no
+        host round trip."""
+        if not (self.world > 1 or self.force):
+            self.global_flags = None
+            return
+        a = self.arena
+        host = torch.tensor([1.0 if id(p) in self.touched else 0.0 for p in a.params], dtype=torch.float32)
+        if a.grad.is_cuda:
+            flags = host.pin_memory().to(a.grad.device, non_blocking=True)
+        else:
+            flags = host
+        if self.native is not None:
+            # the native surface only sums: a sum of 0/1 flags is > 0 exactly where the MAX is 1
+            self.native.all_reduce(flags).wait()
+        else:
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.pg)
+        self.global_flags = flags
 
     def writeback(self, b: int) -> None:
         """comm_dtype buckets: the reduced low-precision sum back into the fp32 arena (the caller has
@@ -303,9 +348,11 @@ class BucketReducer:
     def finish(self) -> float:
         """Flush buckets whose parameters never got a gradient, wait for the exchange and return
         the scale the optimizer must apply to turn the summed gradients into the average."""
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
+        late = [(b, self._launch(b, notify=False)) for b in range(len(self.buckets)) if not self._launched[b]]
+        self._exchange_flags()
+        if self.on_bucket is not None:
+            for b, work in late:
+                self.on_bucket(b, work)
         for b, w in self._works:
             w.wait()
             if self.on_bucket is None:   # (an on_bucket consumer writes back on its own stream)
@@ -419,6 +466,13 @@ class FlatTrainer:
                                "zero_grad() (or use train_step()) so the gradient arena and the bucket "
                                "reducer start from a clean state")
         k = self.accumulate_steps
+        if self._micro >= k and not (self._side is None and self.reducer.world == 1 and not self.reducer.force):
+            # a second backward before optimizer_step(): every bucket of the first pass has already gone out (and, with
+            # the overlapped optimizer, been stepped), so these gradients would be added on top of an already reduced
+            # sum and never exchanged -- the ranks would drift apart without a word
+            raise RuntimeError(f"FlatTrainer.backward() called {self._micro + 1} times before optimizer_step() with "
+                               f"accumulate_steps={k}: construct the trainer with accumulate_steps=<number of "
+                               "micro-batches> (the loss is scaled by 1/k for you) instead of accumulating by hand")
         last = (self._micro + 1) >= k
         # buckets are reduced -- and, with the overlapped optimizer, stepped -- as soon as their gradients
         # are final, which is only true in the last micro-step's backward
@@ -429,12 +483,33 @@ class FlatTrainer:
         (loss / k if k > 1 else loss).backward()
         self.reducer.enabled = True
 
-    def _adamw(self, lo: int, hi: int, step: int, scale_dev: Optional[torch.Tensor] = None) -> None:
+    def _adamw(self, lo: int, hi: int, step: int, scale_dev: Optional[torch.Tensor] = None,
+               gate: Optional[torch.Tensor] = None) -> None:
+        """gate: one fp32 on the device; the launch leaves the range alone when it is 0 (a parameter without a gradient
+        on this rank whose fate depends on the other ranks: BucketReducer._exchange_flags)."""
         from . import ops
         a = self.arena
         ops.adamw_step(a.master[lo:hi], a.grad[lo:hi], self.m[lo:hi], self.v[lo:hi],
                        None if a.shadow is None else a.shadow[lo:hi], self.lr, self.betas[0], self.betas[1],
-                       self.eps, self.weight_decay, step, self._scale, scale_dev=scale_dev)
+                       self.eps, self.weight_decay, step, self._scale, scale_dev=scale_dev, gate=gate)
+
+    def _step_range(self, lo: int, hi: int, step: int, scale_dev: Optional[torch.Tensor] = None) -> None:
+        """AdamW over the trainable parameters inside [lo, hi) that received a gradient -- on this rank (merged plain
+        launches) or, judged on the device by the exchanged flags, on any other rank (one gated launch each)."""
+        for s, e in self._ranges(lo, hi, touched_only=True):
+            self._adamw(s, e, step, scale_dev)
+        flags = self.reducer.global_flags
+        if flags is None:
+            return
+        a = self.arena
+        import bisect
+        i = max(bisect.bisect_right(a.offsets, lo) - 1, 0)
+        while i < len(a.params) and a.offsets[i] < hi:
+            p, o = a.params[i], a.offsets[i]
+            if o >= lo and p.requires_grad and id(p) not in self.reducer.touched:
+                e = a.offsets[i + 1] if i + 1 < len(a.params) else a.numel
+                self._adamw(o, e, step, scale_dev, gate=flags[i:i + 1])
+            i += 1
 
     def _bucket_final(self, b: int, work) -> None:
         """Reducer callback (during backward): step bucket b on the side stream."""
@@ -445,8 +520,7 @@ class FlatTrainer:
             if work is not None:
                 work.wait()                                # the side stream waits for the all-reduce
                 self.reducer.writeback(b)
-            for s, e in self._ranges(lo, hi, touched_only=True):
-                self._adamw(s, e, self.step_count + 1)
+            self._step_range(lo, hi, self.step_count + 1)
         self._stepped.add(b)
 
     def _sumsq(self) -> torch.Tensor:
@@ -474,13 +548,11 @@ class FlatTrainer:
                 norm = self._sumsq().sqrt() * self._scale
                 self.last_grad_norm = norm
                 scale_dev = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0).to(torch.float32).reshape(1)
-            for s, e in self._ranges(0, self.arena.numel, touched_only=True):
-                self._adamw(s, e, self.step_count, scale_dev)
+            self._step_range(0, self.arena.numel, self.step_count, scale_dev)
         else:
             for b, (lo, hi) in enumerate(self.reducer.buckets):
                 if b not in self._stepped:
-                    for s, e in self._ranges(lo, hi, touched_only=True):
-                        self._adamw(s, e, self.step_count)
+                    self._step_range(lo, hi, self.step_count)
             torch.cuda.current_stream().wait_stream(self._side)
         WEIGHT_EPOCH[0] += 1
         self._needs_zero = True
