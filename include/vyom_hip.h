@@ -51,6 +51,12 @@ enum {
 const char* vy_last_error(void);
 int vy_abi_version(void);
 
+/* Launch-sizing hint: the caller is about to run `n` independent launch chains side by side on `n` streams (the
+ * training forward as two batch halves, vyomai_amd/ops.py `lanes`), so each launch should size its grid for 1/n of
+ * the 256 CUs: a 128-tile launch of 256 x 192 tiles is then a full share, not a half-empty chip.  n = 1 (the default)
+ * restores whole-chip sizing.  Process-global, read on the host when a launch is sized; results never depend on it. */
+int vy_set_concurrent_chains(int n);
+
 /* ------------------------------------------------------------------------------------------
  * vy_linear_fwd:  Y[M,N] = act(X[M,K] . W[N,K]^T + bias[N]) + residual[M,N]
  * replaces: nn.Linear call sites -- AttentionSelfOutput.dense + residual add

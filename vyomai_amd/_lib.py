@@ -65,6 +65,7 @@ PROTOTYPES = {
     "vy_ddp_init": [_p, _i, _i],
     "vy_ddp_all_reduce_async": [_p, _i64, _i, _p],
     "vy_ddp_destroy": [],
+    "vy_set_concurrent_chains": [_i],
 }
 OTHER_SYMBOLS = ["vy_last_error", "vy_abi_version", "vy_layernorm_bwd_ws_rows", "vy_decode_ws_bytes",
                  "vy_gemma_ws_bytes", "vy_ddp_world", "vy_ddp_rank"]

@@ -249,6 +249,7 @@ __device__ unsigned long long vy_gemm_clk[6];   // cycles, ticks, launches, prol
 
 // large-M kernel selection knob: VY_GEMM_VARIANT at first use, or vy_debug_set_gemm_variant() (tests and
 // same-process A/B timing; not part of include/vyom_hip.h).  -1 = the default selection.
+int g_chains = 1;   // vy_set_concurrent_chains: launch chains the caller runs side by side
 int g_gemm_variant = -2;
 inline int vy_gemm_variant() {
   if (g_gemm_variant == -2) { const char* e = getenv("VY_GEMM_VARIANT"); g_gemm_variant = e ? atoi(e) : -1; }
@@ -2560,7 +2561,7 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 32);
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<32, 128, 1, 4, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                        st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
-  } else if (M <= 1024 || (mid_tiles && vy_cdiv(M, 256) * vy_cdiv(N, 192) < 160)) {
+  } else if (M <= 1024 || (mid_tiles && vy_cdiv(M, 256) * vy_cdiv(N, 192) * g_chains < 160)) {
     // mid-size M: also whenever the 256 x 192 grid would leave more than a third of the CUs without a tile
     // (M = 2112 rows of a captioning decoder x N = 768: 36 tiles of 256 x 192, 102 of 128 x 128)
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
@@ -2860,6 +2861,11 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
 int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N; }
 
 extern "C" int vy_debug_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
+extern "C" int vy_set_concurrent_chains(int n) {
+  if (n < 1 || n > 8) VY_FAIL(VY_ERR_ARG, "vy_set_concurrent_chains: n = %d (1..8)", n);
+  g_chains = n;
+  return VY_OK;
+}
 
 // measurement aid, not part of include/vyom_hip.h: {shader cycles, 10 ns ticks, launches} since the last call
 extern "C" int vy_debug_gemm_clock(unsigned long long* out3) {   // out3: 6 values

@@ -4,6 +4,7 @@ with create_mask_for_decoder and the batched greedy ``generate``.  All layer mat
 HIP kernels; this file is host-side orchestration."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -86,6 +87,15 @@ class DecoderLayer(nn.Module):
         return self.feed_forward(out, hidden_state), kv_cache
 
 
+def _two_lanes(model, rows: int) -> bool:
+    """Run the training forward as two batch halves on two HIP streams (ops.lanes)?  Only where a half still fills the
+    chip (a 256-row GEMM tile per CU and more) -- VY_LANES=0 / 1 forces either."""
+    env = os.environ.get("VY_LANES")
+    if env is not None:
+        return env != "0"
+    return torch.is_grad_enabled() and model.training and rows >= 8192
+
+
 class DecoderModel(nn.Module, PositionMixin):
     """Reference :278-514."""
 
@@ -120,13 +130,17 @@ class DecoderModel(nn.Module, PositionMixin):
                  attention_mask: Optional[torch.Tensor] = None, ignore_index: int = -100) -> torch.Tensor:
         """Shifted next-token loss (Examples/vyom-ai-decoder_clm.ipynb cell 29) with the LM head and
         the cross-entropy fused (no logits copy)."""
-        hidden_state, _ = self.forward_hidden(input_ids, attention_mask)
-        return self.lm_head.loss(hidden_state, labels, ignore_index)
+        B, L = input_ids.shape
+        with ops.lanes(B, L, _two_lanes(self, B * L)):
+            hidden_state, _ = self.forward_hidden(input_ids, attention_mask)
+            return self.lm_head.loss(hidden_state, labels, ignore_index)
 
     def forward(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 use_cache: Optional[bool] = False, kv_cache=None, start_pos: Optional[int] = 0) -> CLMOutput:
-        hidden_state, kv_cache = self.forward_hidden(input_ids, attention_mask, use_cache, kv_cache, start_pos)
-        logits = self.lm_head(hidden_state)
+        B, L = input_ids.shape
+        with ops.lanes(B, L, not use_cache and _two_lanes(self, B * L)):
+            hidden_state, kv_cache = self.forward_hidden(input_ids, attention_mask, use_cache, kv_cache, start_pos)
+            logits = self.lm_head(hidden_state)
         return CLMOutput(hidden_state=hidden_state, logits=logits, kv_cache=kv_cache)
 
     def create_mask_for_decoder(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,

@@ -17,8 +17,111 @@ from ._lib import call, dtype_code
 Tensor = torch.Tensor
 
 
+# ------------------------------------------------------------------------------------------
+# Two lanes: the training forward as two batch halves on two HIP streams.
+#
+# Every kernel of the block forward is row-separable (GEMM rows, LayerNorm rows, attention batches), so the
+# first B0 sequences can run through the whole stack on the current stream while the remaining ones run through
+# it on a side stream, both writing into the SAME full-batch tensors (which is all the full-batch backward needs).
+# What it buys on MI355X: a K = 768 GEMM launch is a k-loop bound by what the CUs take in from L2 followed by an
+# epilogue in which all 256 workgroups store at once (HBM-bound, matrix pipe idle) -- a third of the launch.  Two
+# independent half-size launch chains drift apart, so one chain's epilogue / LayerNorm / attention softmax runs
+# under the other's MFMA loop.
+#
+# Ordering rules (correct by construction):
+#   * lane 1 waits, before each of its launches, for everything the host has enqueued on the main stream so far
+#     EXCEPT lane 0's launch of the same op (event recorded first): torch ops on the main stream (mask bytes,
+#     casts) are visible to it; it can lag behind lane 0 but never run ahead of the host's program order;
+#   * any op that is not lane-aware, and the end of the region, makes the main stream wait for lane 1 first;
+#   * the region is entered only where every tensor produced inside is kept until after the join (training
+#     forward: saved for backward), so the caching allocator -- which sees main-stream use only -- never hands a
+#     block that lane 1 still touches to someone else.
+# ------------------------------------------------------------------------------------------
+
+
+class _Lanes:
+    active = False
+    side: Optional[torch.cuda.Stream] = None
+    fork_ev: Optional[torch.cuda.Event] = None
+    join_ev: Optional[torch.cuda.Event] = None
+    B = L = B0 = 0
+    dirty = False        # lane 1 has work the main stream has not waited for yet
+    keep: list = []      # every tensor a split launch touched: alive until the join, whatever the caller does with it
+    streams = {}
+
+
+class lanes:
+    """with ops.lanes(B, L, enabled): ... -- see the block comment above.  No-op when not enabled or B < 2."""
+
+    def __init__(self, B: int, L: int, enabled: bool = True):
+        self.on = bool(enabled) and B >= 2 and not _Lanes.active and torch.cuda.is_available()
+        self.B, self.L = B, L
+
+    def __enter__(self):
+        if self.on:
+            dev = torch.cuda.current_device()
+            st = _Lanes.streams.get(dev)
+            if st is None:
+                st = _Lanes.streams[dev] = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+            _Lanes.side, _Lanes.fork_ev, _Lanes.join_ev = st
+            _Lanes.B, _Lanes.L, _Lanes.B0 = self.B, self.L, self.B // 2
+            _Lanes.active, _Lanes.dirty, _Lanes.keep = True, False, []
+            call("vy_set_concurrent_chains", 2)   # (grids are sized on the host, in program order with the launches)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lanes_join()
+            _Lanes.active = False
+            call("vy_set_concurrent_chains", 1)
+            if _Lanes.keep:
+                # the allocator may reuse these blocks for main-stream work from here on: that work is ordered behind
+                # the join just enqueued
+                _Lanes.keep = []
+        return False
+
+
+def _lanes_join() -> None:
+    if _Lanes.active and _Lanes.dirty:
+        _Lanes.join_ev.record(_Lanes.side)
+        torch.cuda.current_stream().wait_event(_Lanes.join_ev)
+        _Lanes.dirty = False
+
+
+def _lane_plan(rows: Optional[int] = None, batches: Optional[int] = None, keep=()):
+    """-> [(first, count, stream)] over rows (of a (B*L, .) view) or batches: one entry when the op runs whole, two
+    when it is split over the lanes."""
+    main = torch.cuda.current_stream()
+    if _Lanes.active:
+        if rows is not None and rows == _Lanes.B * _Lanes.L:
+            cut, n = _Lanes.B0 * _Lanes.L, rows
+        elif batches is not None and batches == _Lanes.B:
+            cut, n = _Lanes.B0, batches
+        else:
+            cut = None
+        if cut is not None:
+            _Lanes.fork_ev.record(main)
+            _Lanes.side.wait_event(_Lanes.fork_ev)
+            _Lanes.dirty = True
+            if keep:
+                _Lanes.keep.extend(t for t in keep if t is not None)
+            return [(0, cut, main.cuda_stream), (cut, n - cut, _Lanes.side.cuda_stream)]
+        _lanes_join()
+    n = rows if rows is not None else batches
+    return [(0, n, main.cuda_stream)]
+
+
 def _stream() -> int:
+    """The stream of an op that always runs whole (inside a lane region: after the main stream has joined lane 1)."""
+    _lanes_join()
     return torch.cuda.current_stream().cuda_stream
+
+
+def _at(t: Optional[Tensor], first: int):
+    """data pointer of t[first:] (None stays None)."""
+    if t is None:
+        return None
+    return t.data_ptr() + first * t.stride(0) * t.element_size()
 
 
 def _ptr(t: Optional[Tensor]):
@@ -70,14 +173,17 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = _lib.
     if p2 is not None:
         assert p2.stride(0) == y2.stride(0)
     if dropout is not None and dropout[0] > 0.0:
+        # (the mask is a function of the global row index: this launch is never split over the lanes)
         assert act == _lib.ACT_NONE and p2 is None
         call("vy_linear_dropout_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
              _ptr(r2), r2.stride(0) if r2 is not None else 0, y2.data_ptr(), y2.stride(0), M, N, K,
              float(dropout[0]), int(dropout[1]), int(dropout[2]), dtype_code(x.dtype), _stream())
         return ret
-    call("vy_linear_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
-         _ptr(r2), r2.stride(0) if r2 is not None else 0, y2.data_ptr(), y2.stride(0), _ptr(p2),
-         M, N, K, act, dtype_code(x.dtype), _stream())
+    whole = _Lanes.active and (x2.data_ptr() != x.data_ptr() or (r2 is not None and r2.data_ptr() != residual.data_ptr()))
+    for m0, m, st in ([(0, M, _stream())] if whole else _lane_plan(rows=M, keep=(x2, r2, y2, p2, w, bias))):
+        call("vy_linear_fwd", _at(x2, m0), x2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
+             _at(r2, m0), r2.stride(0) if r2 is not None else 0, _at(y2, m0), y2.stride(0), _at(p2, m0),
+             m, N, K, act, dtype_code(x.dtype), st)
     return ret
 
 
@@ -91,12 +197,14 @@ def qkv_rope(x: Tensor, w_packed: Tensor, b_packed: Optional[Tensor], h: int, hk
     x2 = _rows(x)
     for t in (q, k, v):
         assert t.stride(3) == 1
-    call("vy_qkv_rope_fwd", x2.data_ptr(), x2.stride(0), w_packed.data_ptr(), w_packed.stride(0),
-         _ptr(b_packed), _ptr(cos), _ptr(sin), pos0,
-         q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
-         k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
-         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
-         B, L, K, h, hk, dh, dtype_code(x.dtype), _stream())
+    whole = _Lanes.active and (x2.data_ptr() != x.data_ptr() or L != _Lanes.L)
+    for b0, nb, st in ([(0, B, _stream())] if whole else _lane_plan(batches=B, keep=(x2, q, k, v, w_packed, b_packed))):
+        call("vy_qkv_rope_fwd", _at(x2, b0 * L), x2.stride(0), w_packed.data_ptr(), w_packed.stride(0),
+             _ptr(b_packed), _ptr(cos), _ptr(sin), pos0,
+             _at(q, b0), q.stride(0), q.stride(1), q.stride(2),
+             _at(k, b0), k.stride(0), k.stride(1), k.stride(2),
+             _at(v, b0), v.stride(0), v.stride(1), v.stride(2),
+             nb, L, K, h, hk, dh, dtype_code(x.dtype), st)
 
 
 def attention(q: Tensor, k: Tensor, v: Tensor, *, causal: bool = False, start_pos: int = 0,
@@ -124,12 +232,16 @@ def attention(q: Tensor, k: Tensor, v: Tensor, *, causal: bool = False, start_po
         am_sl = addmask.stride(2) if addmask.shape[2] > 1 else 0
     if scale is None:
         scale = 1.0 / math.sqrt(dh)
-    call("vy_attn_fwd", q.data_ptr(), q.stride(0), q.stride(1), q.stride(2),
-         k.data_ptr(), k.stride(0), k.stride(1), k.stride(2),
-         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2),
-         out.data_ptr(), out.stride(0), out.stride(1), _ptr(lse), kind, start_pos,
-         _ptr(keypad), keypad.stride(0) if keypad is not None else 0,
-         _ptr(addmask), am_sb, am_sl, B, h, hk, L, S, dh, float(scale), dtype_code(q.dtype), _stream())
+    if lse is not None:
+        assert lse.is_contiguous() and lse.shape == (B, h, L)
+    whole = addmask is not None or (_Lanes.active and L != _Lanes.L)
+    for b0, nb, st in ([(0, B, _stream())] if whole else _lane_plan(batches=B, keep=(q, k, v, out, lse, keypad))):
+        call("vy_attn_fwd", _at(q, b0), q.stride(0), q.stride(1), q.stride(2),
+             _at(k, b0), k.stride(0), k.stride(1), k.stride(2),
+             _at(v, b0), v.stride(0), v.stride(1), v.stride(2),
+             _at(out, b0), out.stride(0), out.stride(1), _at(lse, b0), kind, start_pos,
+             _at(keypad, b0), keypad.stride(0) if keypad is not None else 0,
+             _ptr(addmask), am_sb, am_sl, nb, h, hk, L, S, dh, float(scale), dtype_code(q.dtype), st)
     return out
 
 
@@ -158,8 +270,10 @@ def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float,
     if save_stats:
         mean = torch.empty(M, dtype=torch.float32, device=x.device)
         rstd = torch.empty(M, dtype=torch.float32, device=x.device)
-    call("vy_layernorm_fwd", x2.data_ptr(), x2.stride(0), gamma.data_ptr(), beta.data_ptr(),
-         y.data_ptr(), y.stride(0), _ptr(mean), _ptr(rstd), M, N, float(eps), dtype_code(x.dtype), _stream())
+    whole = _Lanes.active and x2.data_ptr() != x.data_ptr()
+    for m0, m, st in ([(0, M, _stream())] if whole else _lane_plan(rows=M, keep=(x2, y, mean, rstd, gamma, beta))):
+        call("vy_layernorm_fwd", _at(x2, m0), x2.stride(0), gamma.data_ptr(), beta.data_ptr(),
+             _at(y, m0), y.stride(0), _at(mean, m0), _at(rstd, m0), m, N, float(eps), dtype_code(x.dtype), st)
     return y.view(x.shape), mean, rstd
 
 
