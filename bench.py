@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the configs[3] / configs[4] side measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher rehearsal (runs without a GPU): every rank joins the process group, meets the barrier and "
+                         "rank 0 prints a line with n_gpus = the world size -- no kernels, not a benchmark line")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal on a one-GPU box: a ONE-rank process group whose bucket collectives are really issued "
                          "(RCCL init, async all-reduce, stream waits, barrier); not a benchmark configuration")
@@ -250,8 +253,154 @@ def cpu_baseline(cfg, seq):
                        "sample": f"B=1 greedy decode, static cache, {new} tokens behind a 64-token prompt (token loop only)"}}
 
 
+def build_text_model(cfg, attn, B, L, dev, rank):
+    import vyomai_amd as V
+    from vyomai_amd import recipe
+    from vyomai_amd.training import FlatTrainer
+    with contextlib.redirect_stdout(sys.stderr):   # (the constructors print the reference's notices; stdout is the JSON line's)
+        model = V.DecoderModel(cfg, "rope", None if attn == "none" else "gqa")
+    recipe.load_recipe_(model)
+    model = model.to(dev).train()
+    trainer = FlatTrainer(model, lr=5e-5, weight_decay=0.01)
+    torch.manual_seed(1234 + rank)
+    ids = torch.randint(3, cfg.vocab_size, (B, L), device=dev)
+    return model, trainer, ids
+
+
+def time_training(trainer, model, ids, steps, warmup, barrier, dev, dist_on):
+    """warmup untimed steps, then exactly `steps` steps between two barrier + synchronize pairs -> (max over ranks of
+    the wall time, last loss)."""
+    import torch.distributed as dist
+
+    def step():
+        return trainer.train_step(lambda: model.clm_loss(ids, ids))
+
+    loss = None
+    for _ in range(warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist_on:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), loss
+
+
+def time_decode(model, cfg, attn, ids, new_tokens, dev, world, dist_on):
+    """KV-cache greedy decode behind the (B, L) prompts, static cache: time per token step from two runs (1 and n new
+    tokens), and the HBM roofline of a step -- every layer / head weight once (the embedding table only B rows) + the
+    K/V cache of the average context of the timed steps, over the measured step time."""
+    import torch.distributed as dist
+    B, L = ids.shape
+    model.eval()
+    with torch.no_grad():
+        am = torch.ones(B, L, dtype=torch.long, device=dev)
+
+        def gen(n):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            model.generate(ids, am, max_len=n, use_cache=True, use_static_cache=True)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t
+        gen(2)
+        t1 = gen(1)
+        tn = gen(new_tokens)
+    model.train()
+    per_tok = (tn - t1) / max(1, new_tokens - 1)
+    tm = torch.tensor([per_tok], device=dev, dtype=torch.float64)
+    if dist_on:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    per_tok = float(tm.item())
+    d_, nl, h = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads
+    hk = getattr(cfg, "num_key_value_heads", h) if attn == "gqa" else h
+    dh = d_ // h
+    wbytes = (nl * (8 * d_ * d_ + 2 * d_ * d_ + 2 * d_ * hk * dh) + d_ * d_ + cfg.vocab_size * d_) * 2
+    ctx = L + (new_tokens + 1) / 2.0
+    kvbytes = 2 * nl * B * ctx * hk * dh * 2
+    return {"tokens_per_sec": round(world * B / per_tok, 1), "ms_per_token_step": round(per_tok * 1e3, 3),
+            "prefill_plus_first_token_ms": round(t1 * 1e3, 2), "batch": B, "prompt": L,
+            "new_tokens": new_tokens, "cache": "StaticCacheOne", "scaling": "replicas only",
+            "roofline": {"bound": "hbm", "achieved": round((wbytes + kvbytes) / per_tok * 1e-9, 1),
+                         "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round((wbytes + kvbytes) / per_tok * 1e-9 / PEAK_HBM_GBS, 4),
+                         "bytes_per_step": int(wbytes + kvbytes),
+                         "note": f"algorithmic bytes: weights once ({wbytes / 1e6:.0f} MB) + K/V of the mean context "
+                                 f"({kvbytes / 1e6:.0f} MB); a step is a chain of dependent launches, only the attention "
+                                 "launch is bandwidth-bound (DESIGN section 3)"}}
+
+
+def gqa_side_config(a, dev, rank, world, barrier, dist_on):
+    """BASELINE.md section 4 / SURVEY section 8d name two attention types for the headline: attention_type=None (the
+    headline itself) and 'gqa' with 4 key/value heads (reference models/decoder.py:116-201).  The same step and the same
+    decode on the GQA model, a few steps."""
+    a2 = argparse.Namespace(**vars(a))
+    a2.attn = "gqa"
+    cfg = make_cfg(a2)
+    model, trainer, ids = build_text_model(cfg, "gqa", a.batch, a.seq, dev, rank)
+    steps = min(a.steps, 8)
+    dt, loss = time_training(trainer, model, ids, steps, 2, barrier, dev, dist_on)
+    out = {"workload": "configs[1] with attention_type='gqa' (num_key_value_heads=4): the same CLM training step and KV-cache "
+                       "greedy decode", "ms_per_step": round(dt / steps * 1e3, 3),
+           "tokens_per_sec": round(world * a.batch * a.seq * steps / dt, 1), "loss": round(float(loss.item()), 4)}
+    if not a.no_decode:
+        dec = time_decode(model, cfg, "gqa", ids, a.decode_tokens, dev, world, dist_on)
+        out["decode"] = {k: dec[k] for k in ("tokens_per_sec", "ms_per_token_step", "prefill_plus_first_token_ms", "roofline")}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as a CHILD
+    torch.distributed.run process (nothing in this process has touched the GPU yet; a process that has must never exec
+    another program), hand its stdout -- rank 0's one JSON line -- through and return its exit code."""
+    import socket
+    import subprocess
+    so = socket.socket()
+    so.bind(("127.0.0.1", 0))
+    port = so.getsockname()[1]
+    so.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def rehearse_launch(a) -> None:
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.backend if a.backend != "nccl" or torch.cuda.is_available() else "gloo")
+        dist.barrier()
+        t = torch.ones(1)
+        if dist.get_backend() == "nccl":
+            t = t.cuda(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
+        dist.all_reduce(t)
+        assert int(t.item()) == world
+    if rank == 0:
+        print(json.dumps({"metric": "launcher rehearsal", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "rehearsal": "launch only: process group, barrier and one all-reduce; no kernels"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a))
+    if int(env_world or "1") != a.gpus:
+        # never print a line whose n_gpus differs from what was asked for
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={env_world} ranks")
+    if a.rehearse_launch:
+        return rehearse_launch(a)
     # stdout carries ONE JSON line: native libraries write there too (RCCL prints a five-line version banner to fd 1 when
     # the communicator is created), so fd 1 is pointed at stderr for the run and the line goes out through a saved copy
     sys.stdout.flush()
@@ -283,87 +432,24 @@ def main():
         so.close()
         dist.init_process_group(a.backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
 
-    import vyomai_amd as V
-    from vyomai_amd import recipe
-    from vyomai_amd.training import FlatTrainer
-
     cfg = make_cfg(a)
-    at = None if a.attn == "none" else "gqa"
-    with contextlib.redirect_stdout(sys.stderr):   # (the constructors print the reference's notices; stdout is the JSON line's)
-        model = V.DecoderModel(cfg, "rope", at)
-    recipe.load_recipe_(model)
-    model = model.to(dev).train()
-    trainer = FlatTrainer(model, lr=5e-5, weight_decay=0.01)
     B, L = a.batch, a.seq
-    torch.manual_seed(1234 + rank)
-    ids = torch.randint(3, cfg.vocab_size, (B, L), device=dev)
+    dist_on = world > 1 or a.force_dist
 
     def barrier():
-        if world > 1 or a.force_dist:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        return trainer.train_step(lambda: model.clm_loss(ids, ids))
-
-    for _ in range(a.warmup):
-        loss = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1 or a.force_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    model, trainer, ids = build_text_model(cfg, a.attn, B, L, dev, rank)
+    dt, loss = time_training(trainer, model, ids, a.steps, a.warmup, barrier, dev, dist_on)
     tokens = world * B * L * a.steps
     final_loss = float(loss.item())
 
     # ---- decode: replicas only (independent sequences per GPU, no collective) -------------------
     dec = None
     if not a.no_decode:
-        model.eval()
-        with torch.no_grad():
-            am = torch.ones(B, L, dtype=torch.long, device=dev)
-            mb = model  # fp32 masters + bf16 shadows: run the decode in bf16 via compute_dtype
-            torch.cuda.synchronize()
-            # prefill + n tokens; time the token loop only via two runs (n and 1 new tokens)
-            def gen(n):
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                mb.generate(ids, am, max_len=n, use_cache=True, use_static_cache=True)
-                torch.cuda.synchronize()
-                return time.perf_counter() - t
-            gen(2)
-            t1 = gen(1)
-            tn = gen(a.decode_tokens)
-            per_tok = (tn - t1) / max(1, a.decode_tokens - 1)
-            tm = torch.tensor([per_tok], device=dev, dtype=torch.float64)
-            if world > 1 or a.force_dist:
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            per_tok = float(tm.item())
-            # decode roofline (HBM): per token step every layer / head weight once (the embedding table only B
-            # rows) + the K/V cache of the average context of the timed steps, over the measured step time
-            d_, nl = cfg.hidden_size, cfg.num_hidden_layers
-            hk = getattr(cfg, "num_key_value_heads", cfg.num_attention_heads) if a.attn == "gqa" else cfg.num_attention_heads
-            wbytes = (nl * 12 * d_ * d_ + d_ * d_ + cfg.vocab_size * d_) * 2
-            if a.attn == "gqa":
-                wbytes -= nl * 2 * d_ * (d_ - hk * (d_ // cfg.num_attention_heads)) * 2
-            ctx = L + (a.decode_tokens + 1) / 2.0
-            kvbytes = 2 * nl * B * ctx * hk * (d_ // cfg.num_attention_heads) * 2
-            dec = {"tokens_per_sec": round(world * B / per_tok, 1), "ms_per_token_step": round(per_tok * 1e3, 3),
-                   "prefill_plus_first_token_ms": round(t1 * 1e3, 2), "batch": B, "prompt": L,
-                   "new_tokens": a.decode_tokens, "cache": "StaticCacheOne", "scaling": "replicas only",
-                   "roofline": {"bound": "hbm", "achieved": round((wbytes + kvbytes) / per_tok * 1e-9, 1),
-                                "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": round((wbytes + kvbytes) / per_tok * 1e-9 / PEAK_HBM_GBS, 4),
-                                "bytes_per_step": int(wbytes + kvbytes),
-                                "note": "algorithmic bytes: weights once (249 MB) + K/V of the mean context; 7 dependent launches per "
-                                        "layer, each ~1.3 us of boundary + 2-3 us until its loads have arrived; only the attention "
-                                        "launch (57 MB of K/V per layer) is bandwidth-bound (DESIGN section 3, round 2 second half)"}}
-        model.train()
+        dec = time_decode(model, cfg, a.attn, ids, a.decode_tokens, dev, world, dist_on)
 
     roof = cpu = None
     others = None
@@ -400,6 +486,12 @@ def main():
                 others["configs[1] with 25 % right padding"] = {"error": f"{type(ex).__name__}: {ex}"}
         del trainer, model
         torch.cuda.empty_cache()
+        try:
+            others["configs[1] gqa"] = gqa_side_config(a, dev, rank, world, barrier, dist_on)
+        except Exception as ex:   # noqa: BLE001
+            others["configs[1] gqa"] = {"error": f"{type(ex).__name__}: {ex}"}
+            if world > 1:
+                raise
         todo = [("configs[3]", "tools.bench_vlm_training")]
         if world == 1:
             todo.append(("configs[4]", "tools.bench_paligemma"))
@@ -439,7 +531,7 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     os.close(json_fd)
-    if world > 1 or a.force_dist:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -278,13 +278,18 @@ def test_out_of_range_labels_are_ignored_and_flagged():
     # the mean must not count the bad row on either path -- the same loss as with that label set to ignore_index
     asign = bad.clone()
     asign[0, 3] = -100
+    m.eval()                                   # (the model was built with the default dropout: no random masks here)
+    loss = m.clm_loss(ids, bad)
+    m.lm_head.label_error.zero_()
     want = m.clm_loss(ids, asign)
-    assert abs(float(loss) - float(want)) < 1e-6, (float(loss), float(want))      # fused (bf16, V <= 65536) path
-    m32 = Vm.DecoderModel(cfg, "rope", None).to(DEV).train()
+    assert abs(float(loss) - float(want)) < 2e-5, (float(loss), float(want))      # fused (bf16, V <= 65536) path
+    m32 = Vm.DecoderModel(cfg, "rope", None).to(DEV).eval()
     m32.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
     l32, w32 = m32.clm_loss(ids, bad), m32.clm_loss(ids, asign)                  # two-pass path (fp32)
-    assert abs(float(l32) - float(w32)) < 1e-6
+    assert abs(float(l32) - float(w32)) < 2e-5
     assert abs(float(l32) - float(loss)) < 5e-2                                  # the two paths agree on the scale
+    m.train()
+    m.lm_head.label_error.zero_()
     m.clm_loss(ids, ids)
     m.lm_head.raise_on_label_error()                                # clean labels: no error
 

@@ -249,3 +249,50 @@ def test_deferred_weight_gradient_bookkeeping():
     p._vy_deferred = False
     BucketReducer._hook(Fake(), p)
     assert seen == [p]
+
+
+def test_bench_starts_its_own_ranks_and_never_misreports_n_gpus():
+    """`python bench.py --gpus N` without a launcher used to run ONE rank and print n_gpus: 1.  Now it starts
+    the N ranks itself (a child torch.distributed.run), and refuses a world size that differs from --gpus."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--rehearse-launch", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True,
+                         timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    env["WORLD_SIZE"] = "4"
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-launch"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and not bad.stdout.strip()
+
+
+def test_wrapped_projection_is_refused_not_ignored():
+    """The reference's adapters replace attention.query by a wrapper holding the Linear at `.linear`
+    (layers/adapters.py:21-24): the fused QKV path must say that it cannot honour it, not silently drop it."""
+    import torch.nn as nn
+    import vyomai_amd as V
+    from vyomai_amd._lib import VyomHipError
+
+    class LoraLike(nn.Module):
+        def __init__(self, linear):
+            super().__init__()
+            self.linear = linear
+            self.lora_a = nn.Parameter(torch.zeros(4, linear.in_features))
+            self.lora_b = nn.Parameter(torch.zeros(linear.out_features, 4))
+
+    cfg = cases.micro_cfg()
+    layer = V.DecoderModel(cfg, "rope", None).all_layer[0]
+    layer.attention._packed()                       # plain projections: fine
+    layer.attention.query = LoraLike(layer.attention.query)
+    with pytest.raises(VyomHipError, match="LoraLike"):
+        layer.attention._packed()
+    with pytest.raises(VyomHipError, match="merge the low-rank update"):
+        layer.attention._params()

@@ -33,12 +33,32 @@ def run(new_tokens: int = 64, dev=None):
     t1 = go(1)
     tn = go(new_tokens)
     per = (tn - t1) / (new_tokens - 1)
-    streamed = (nparam - sum(p.numel() for p in m.vision_tower.parameters())) * 2
+    nvis = sum(p.numel() for p in m.vision_tower.parameters())
+    streamed = (nparam - nvis) * 2
+    # K/V read per token step: 18 layers x 1 KV head x dh 256 x the mean context of the timed steps (264 prompt slots + n/2)
+    ctx = 264 + new_tokens / 2.0
+    kv = 2 * txt.num_hidden_layers * txt.num_key_value_heads * txt.head_dim * ctx * 2
+    # prefill: every weight once (vision tower + projector + language model + the tied vocabulary matrix as the head of the
+    # one scored position) is the HBM floor; its FLOPs (2 x parameters x rows: 256 patch rows in the tower, 264 rows in
+    # the language model, the head on one row) price the same pass on the matrix pipe
+    pre_bytes = nparam * 2
+    nhead = txt.vocab_size * txt.hidden_size
+    pre_flops = 2.0 * (nvis * 256 + (nparam - nvis - nhead) * 264 + nhead)
+    t_pre = max(t1 - per, 1e-9)      # (the first call also decodes one token)
     return {"workload": "configs[4]: PaliGemma shape (SigLIP-So400m 27L + Gemma-2B 18L, MQA dh=256, vocab 257216), random init, "
                         "bf16, B=1, 224x224 image + 8 text tokens, KV-cache greedy decode",
             "parameters": nparam, "prefill_plus_first_token_ms": round(t1 * 1e3, 2), "ms_per_token": round(per * 1e3, 3),
             "decode_tokens_per_sec": round(1 / per, 1), "new_tokens": new_tokens,
-            "weight_stream_TBps": round(streamed / per * 1e-12, 2)}
+            "weight_stream_TBps": round(streamed / per * 1e-12, 2),
+            "roofline": {"decode": {"bound": "hbm", "achieved": round((streamed + kv) / per * 1e-9, 1), "peak": 8000.0, "unit": "GB/s",
+                                    "frac": round((streamed + kv) / per * 1e-9 / 8000.0, 4), "bytes_per_token": int(streamed + kv)},
+                         "prefill": {"bound": "hbm", "achieved": round(pre_bytes / t_pre * 1e-9, 1), "peak": 8000.0, "unit": "GB/s",
+                                     "frac": round(pre_bytes / t_pre * 1e-9 / 8000.0, 4), "bytes": int(pre_bytes),
+                                     "ms": round(t_pre * 1e3, 2), "mfma_TFLOPs": round(pre_flops / t_pre * 1e-12, 1),
+                                     "mfma_frac": round(pre_flops / t_pre * 1e-12 / 2500.0, 4),
+                                     "note": "weights once = 5.85 GB -> 0.73 ms at 8 TB/s; 1.5 TFLOP -> 0.6 ms at 2.5 PFLOP/s: the "
+                                             "weight stream bounds the 264-row prefill"},
+                         "profile": "profiles/r03_paligemma_prefill_kernel_stats.csv"}}
 
 
 if __name__ == "__main__":

@@ -38,6 +38,11 @@ _s = socket.socket(); _s.bind(("127.0.0.1", 0)); _port = _s.getsockname()[1]; _s
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_port}", rank=0, world_size=1, device_id=dev)
 got, loss_got, tr = train()
 assert tr.reducer.force and len(tr.reducer.launch_order) == len(tr.reducer.buckets) > 1
+# per step: one all-reduce per bucket, in bucket order, + the one-element-per-parameter flag exchange
+per_step = len(tr.reducer.buckets) + 1
+assert tr.reducer.launch_order == list(range(len(tr.reducer.buckets)))
+assert tr.reducer.collectives == 3 * per_step, (tr.reducer.collectives, per_step)
+torch_path_collectives = tr.reducer.collectives
 d = (got - ref).abs()
 print(f"fp32 buckets over RCCL: loss {loss_got:.6f} vs {loss_ref:.6f}; max |param diff| {d.max().item():.3e} mean {d.mean().item():.3e}")
 print(f"run-to-run noise of the trainer without a group: mean {noise:.3e}")
@@ -52,6 +57,10 @@ dist.destroy_process_group()
 # no torch.distributed group at all
 gotn, lossn, trn = train(native_rccl=True)
 assert trn.native is not None and trn.reducer.native is trn.native and trn.native.world == 1
+# the native transport issued exactly the collectives the torch.distributed transport issued, every one through vy_ddp_*
+assert trn.reducer.collectives == torch_path_collectives == trn.native.issued, \
+    (trn.reducer.collectives, torch_path_collectives, trn.native.issued)
+print(f"collectives over 3 steps: torch.distributed {torch_path_collectives}, native {trn.native.issued}")
 dn = (gotn - ref).abs()
 print(f"fp32 buckets over the native communicator: loss {lossn:.6f}; max |param diff| {dn.max().item():.3e} mean {dn.mean().item():.3e}")
 assert dn.mean().item() <= 3 * noise + 1e-6 and abs(lossn - loss_ref) < 1e-3

@@ -1124,15 +1124,41 @@ extern "C" int vy_debug_mfma_peak(int workgroups, int iters, float* sink, void* 
   VY_CHECK_LAUNCH("vy_debug_mfma_peak");
   return VY_OK;
 }
-// A plain 16-byte-per-lane copy (read n bytes + write n bytes).
+// The HBM ceiling probe: a copy (read n bytes + write n bytes) with eight 16-byte loads in flight per lane before the
+// first store, a workgroup walking contiguous 32 KiB pieces (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy; the
+// one-load-per-iteration loop this replaces reached 4.6-4.7).  MODE bit 0: non-temporal loads, bit 1: non-temporal stores.
+template <int MODE>
 __global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n16) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n16; i += stride) dst[i] = src[i];
+  constexpr int U = 8;
+  const int64_t piece = 256 * U;
+  const int64_t npieces = n16 / piece;
+  for (int64_t p = blockIdx.x; p < npieces; p += gridDim.x) {
+    const f32x4* s = src + p * piece + threadIdx.x;
+    f32x4* d = dst + p * piece + threadIdx.x;
+    f32x4 v[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) v[j] = (MODE & 1) ? __builtin_nontemporal_load(s + j * 256) : s[j * 256];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (MODE & 2) __builtin_nontemporal_store(v[j], d + j * 256);
+      else d[j * 256] = v[j];
+    }
+  }
+  for (int64_t i = npieces * piece + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
 extern "C" int vy_debug_copy(const void* src, void* dst, int64_t bytes, void* stream) {
   if (!src || !dst || bytes % 16) VY_FAIL(VY_ERR_ARG, "vy_debug_copy: bad arguments");
-  hipLaunchKernelGGL(copy16_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
+  static const int mode = [] { const char* e = getenv("VY_COPY_MODE"); return e ? atoi(e) : 3; }();
+  static const int wgs = [] { const char* e = getenv("VY_COPY_WGS"); return e ? atoi(e) : 256 * 8; }();
+  const dim3 g(wgs), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  const f32x4* s = (const f32x4*)src; f32x4* d = (f32x4*)dst; const int64_t n16 = bytes / 16;
+  switch (mode & 3) {
+    case 0: hipLaunchKernelGGL(copy16_kernel<0>, g, b, 0, st, s, d, n16); break;
+    case 1: hipLaunchKernelGGL(copy16_kernel<1>, g, b, 0, st, s, d, n16); break;
+    case 2: hipLaunchKernelGGL(copy16_kernel<2>, g, b, 0, st, s, d, n16); break;
+    default: hipLaunchKernelGGL(copy16_kernel<3>, g, b, 0, st, s, d, n16); break;
+  }
   VY_CHECK_LAUNCH("vy_debug_copy");
   return VY_OK;
 }

@@ -127,6 +127,7 @@ class _SelfAttentionBase(nn.Module):
         """The three projection weights as ONE (Nq+2Nkv, K) matrix for the fused kernel.  The
         nn.Linear parameters stay (state_dict names, LoRA wrapping) but are re-pointed to be
         views of one packed buffer the first time, or after .to()/load_state_dict moved them."""
+        self._plain_projections()
         if self._fused_qkv:
             return self.qkv.weight, self.qkv.bias
         ws = [self.query.weight, self.key.weight, self.value.weight]
@@ -174,6 +175,20 @@ class _SelfAttentionBase(nn.Module):
                 off += b.shape[0]
         return self._packed_w, self._packed_b
 
+    def _plain_projections(self) -> None:
+        """The fused QKV kernel reads query/key/value.weight itself and never calls the sub-modules, so a projection that
+        has been replaced by a wrapper -- the reference's adapters swap `attention.query` for a LoraLinear / DoraLinear
+        whose weight lives at `.linear.weight` (VyomAI/layers/adapters.py:21-24, 58-62) -- would be ignored (or crash on
+        a missing attribute).  Adapters are outside SURVEY section 8; say so instead of computing without them."""
+        for name in (("qkv",) if self._fused_qkv else ("query", "key", "value")):
+            m = getattr(self, name)
+            if not isinstance(m, nn.Linear):
+                raise VyomHipError(
+                    f"attention.{name} is a {type(m).__name__}, not an nn.Linear: the MI355X attention path reads the "
+                    "projection weights directly (one fused QKV launch) and would skip the wrapper's extra term.  "
+                    "Adapter wrappers (LoRA / DoRA) are out of scope here -- merge the low-rank update into "
+                    f"`{name}.weight` (W + alpha * B A) and restore the nn.Linear before running on the HIP path.")
+
     def _packed_shadow(self, dtype: torch.dtype) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """_packed() in the compute dtype.  The packed buffer has a version counter of its own that
         in-place writes to query/key/value.weight (optimizer.step() of a torch optimizer,
@@ -203,6 +218,7 @@ class _SelfAttentionBase(nn.Module):
         return sw, sb
 
     def _params(self):
+        self._plain_projections()
         if self._fused_qkv:
             return [self.qkv.weight, self.qkv.bias]
         ps = [self.query.weight, self.key.weight, self.value.weight]

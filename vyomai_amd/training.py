@@ -175,11 +175,13 @@ class NativeComm:
         _lib.call("vy_ddp_init", uid.data_ptr(), rank, world)
         self.world, self.rank = world, rank
         self.stream = torch.cuda.Stream(device=device)
+        self.issued = 0   # vy_ddp_all_reduce_async calls
 
     def all_reduce(self, view: torch.Tensor) -> _StreamWork:
         self.stream.wait_stream(torch.cuda.current_stream())
         self._lib.call("vy_ddp_all_reduce_async", view.data_ptr(), view.numel(), self._lib.dtype_code(view.dtype),
                        self.stream.cuda_stream)
+        self.issued += 1
         return _StreamWork(self.stream.record_event())
 
     def close(self) -> None:
@@ -206,6 +208,7 @@ class BucketReducer:
         self.average = average
         self.comm_dtype = comm_dtype
         self.enabled = True   # False during the non-final micro-steps of gradient accumulation
+        self.collectives = 0  # all-reduces issued since construction, by either transport (tools/check_rccl_one_rank.py)
         # buckets over the arena in REVERSE order: backward reaches the last layers first.  Only
         # parameters that require gradients are waited for; a frozen one never reports.
         self.buckets: List[Tuple[int, int]] = []      # (start, end) element ranges
@@ -310,6 +313,7 @@ class BucketReducer:
                 work = self.native.all_reduce(view)
             else:
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self.collectives += 1
             self._works.append((b, work))
         if notify and self.on_bucket is not None:
             self.on_bucket(b, work)
@@ -336,6 +340,7 @@ class BucketReducer:
             self.native.all_reduce(flags).wait()
         else:
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.pg)
+        self.collectives += 1
         self.global_flags = flags
 
     def writeback(self, b: int) -> None:
