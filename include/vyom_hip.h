@@ -57,6 +57,13 @@ int vy_abi_version(void);
  * restores whole-chip sizing.  Process-global, read on the host when a launch is sized; results never depend on it. */
 int vy_set_concurrent_chains(int n);
 
+/* Scratch for the launches on `stream` (the library never allocates device memory): mid-size GEMMs (32 < M <= ~2304 rows,
+ * fewer than 300 tiles of 128 x 128) split K over workgroups and keep fp32 partial tiles here between their two launches
+ * -- 64 KiB per (tile, slice), at most 512 of them = 32 MiB.  One workspace per stream (launches on one stream are
+ * ordered, so they can share it); ws = NULL or bytes = 0 removes the entry.  Without a workspace such GEMMs run unsplit:
+ * results are the same up to the fp32 summation order over K. */
+int vy_workspace_set(void* stream, void* ws, int64_t bytes);
+
 /* ------------------------------------------------------------------------------------------
  * vy_linear_fwd:  Y[M,N] = act(X[M,K] . W[N,K]^T + bias[N]) + residual[M,N]
  * replaces: nn.Linear call sites -- AttentionSelfOutput.dense + residual add

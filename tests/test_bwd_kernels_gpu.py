@@ -59,7 +59,9 @@ def test_wgrad_grouped():
         ops.linear_wgrad_grouped([(items[0][0][:, :767], items[0][1][:, :767], items[0][2][:767, :767], None)])   # K % 8
 
 
-@pytest.mark.parametrize("M,N,K,act", [(300, 768, 3072, 1), (1024, 768, 768, 0), (51, 3072, 768, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(300, 768, 3072, 1), (1024, 768, 768, 0), (51, 3072, 768, 0),
+                                       # split-K launches (mid-size M, few tiles): the decoder rows of configs[3], a 264-row prefill
+                                       (2112, 3072, 768, 0), (2112, 768, 3072, 1), (264, 2048, 2048, 0), (264, 16384, 2048, 0)])
 def test_dgrad(M, N, K, act):
     """dX[M,K] = dY[M,N] @ W[N,K] (* gelu'(pre)) (+ add)."""
     ops = _ops()

@@ -51,7 +51,12 @@ ACTS = {0: lambda x: x, 1: O.gelu_erf, 2: O.gelu_tanh}
                                    # <= 4 rows: the matrix-vector kernel (one wave per output column)
                                    (1, 2048, 16384), (2, 1003, 768), (3, 770, 264), (4, 768, 3072), (1, 5, 8),
                                    # > 1024 rows: the 256 x 192 tile kernel (M / N / K tails)
-                                   (2000, 768, 768), (4096, 1003, 768), (1500, 384, 72), (3072, 3072, 768)])
+                                   (2000, 768, 768), (4096, 1003, 768), (1500, 384, 72), (3072, 3072, 768),
+                                   # mid-size M with few tiles: K split over workgroups (fp32 partial tiles + finish launch):
+                                   # PaliGemma-shape prefill (264 rows; Gemma out-projection, SigLIP fc1 / fc2 with a K tail) and
+                                   # the 2112 rows of the captioning decoder (configs[3])
+                                   (264, 2048, 2048), (264, 2048, 16384), (256, 4304, 1152), (256, 1152, 4304), (2112, 768, 3072),
+                                   (2112, 768, 768)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_linear_bf16(M, N, K, act):
     ops, _ = _ops()
@@ -70,6 +75,36 @@ def test_linear_bf16(M, N, K, act):
     # no bias / no residual / no pre path
     y2 = ops.linear(x.to(DEV), w.to(DEV))
     check(y2, x.double() @ w.double().t(), 3e-2, 1e-2, "linear bf16 plain")
+
+
+def test_linear_bf16_wide_mid_m_and_split_k_equals_unsplit():
+    """(264, 32768, 2048): Gemma's gate/up projection at prefill (768 tiles: not split).  And the split launches against
+    the same GEMM without a workspace (one workgroup per tile walks all of K): equal up to the fp32 summation order."""
+    ops, lib = _ops()
+    M, N, K = 264, 32768, 2048
+    x = rnd(M, K, seed=1).bfloat16().to(DEV)
+    w = rnd(N, K, seed=2, scale=1 / math.sqrt(K)).bfloat16().to(DEV)
+    y = ops.linear(x, w)
+    cols = torch.arange(0, N, 37, device=DEV)
+    check(y[:, cols], x.double() @ w[cols].double().t(), 3e-2, 1e-2, "gate/up shape")
+    from vyomai_amd._lib import call
+    for (M, N, K) in [(264, 2048, 16384), (256, 1152, 4304), (2112, 768, 3072)]:
+        x = rnd(M, K, seed=3).bfloat16().to(DEV)
+        w = rnd(N, K, seed=4, scale=1 / math.sqrt(K)).bfloat16().to(DEV)
+        b = rnd(N, seed=5, scale=0.1).bfloat16().to(DEV)
+        r = rnd(M, N, seed=6).bfloat16().to(DEV)
+        split = ops.linear(x, w, b, act=1, residual=r)
+        st = torch.cuda.current_stream()
+        call("vy_workspace_set", st.cuda_stream, None, 0)            # no workspace: the one-launch kernel
+        ops._WS.pop((st.device_index, st.cuda_stream), None)
+        try:
+            import vyomai_amd.ops as O_
+            saved, O_._mid_ws = O_._mid_ws, lambda rows: None
+            whole = ops.linear(x, w, b, act=1, residual=r)
+        finally:
+            O_._mid_ws = saved
+        d = (split.float() - whole.float()).abs().max().item()
+        assert d <= 2 ** -6 * max(1.0, whole.float().abs().max().item()), (M, N, K, d)   # a bf16 rounding step at most
 
 
 @pytest.mark.parametrize("M,N,K", [(51, 1003, 768), (130, 64, 16), (64, 64, 4), (257, 192, 260)])

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "vy_ddp_all_reduce_async": [_p, _i64, _i, _p],
     "vy_ddp_destroy": [],
     "vy_set_concurrent_chains": [_i],
+    "vy_workspace_set": [_p, _p, _i64],
 }
 OTHER_SYMBOLS = ["vy_last_error", "vy_abi_version", "vy_layernorm_bwd_ws_rows", "vy_decode_ws_bytes",
                  "vy_gemma_ws_bytes", "vy_ddp_world", "vy_ddp_rank"]

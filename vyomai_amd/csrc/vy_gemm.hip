@@ -26,6 +26,7 @@ int vy_rope_qk(void* q, int64_t q_sb, int64_t q_sh, int64_t q_sl, int hq, void* 
                int dtype, hipStream_t st);
 
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -1214,6 +1215,214 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_m16_kernel(
     if (kt + 1 < KT) read_frags(wa[0] + (STAGE - boff), xa[0] + (STAGE - boff), wf[0], xf[0]);
   }
   gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD, 1, true, true>(acc, smem, m0, n0, M, N, ep, eq);
+}
+
+// ------------------------------------------------------------------------------------------
+// Split-K for mid-size M (32 < M <= ~2304 rows: a 264-row PaliGemma prefill, the 2112 rows of a captioning decoder).
+// A 264 x 2048 output is 48 tiles of 128 x 128 -- 48 of 256 CUs -- and with K = 16384 (Gemma's down-projection) each of
+// them walks 256 k-stages alone.  Here the K range is cut into S slices: tiles x S workgroups (~two per CU) each run the
+// k-loop of gemm_nt_bf16_m16_kernel<128, 128> over their slice and leave the fp32 accumulators in the workspace AS THEY SIT
+// IN THE REGISTERS ([slice][tile][wave][block][lane] x f32x4: every wave-instruction stores 1 KiB contiguously, no staging);
+// gemm_splitk_finish_kernel -- one workgroup per tile with the same thread geometry -- adds the S slices in slice order
+// (deterministic) and runs the ordinary staged epilogue (bias, activation, residual, saved pre-activation, dgrad operands,
+// QKV head split / RoPE).  Workgroup -> (slice, tile): the workgroups of one XCD (b mod 8) work on ONE k-slice where S
+// divides 8, so an XCD's L2 sees only its K range of X and W (speed only).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void splitk_block_of(int b, int tiles, int S, int& tile, int& slice) {
+  if (S <= 8 && (8 % S) == 0 && ((tiles * S) & 7) == 0) {
+    const int xcd = b & 7, j = b >> 3, per = 8 / S;       // `per` XCDs share a slice
+    slice = xcd % S;
+    tile = j * per + xcd / S;
+  } else {
+    slice = b % S;
+    tile = b / S;
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_m16_splitk_kernel(
+    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
+    int K, int tiles_n, int tiles, int S, int kt_per, float* __restrict__ ws) {
+  constexpr int NW = WGM * WGN;
+  constexpr int TM = BM / (16 * WGM), TN = BN / (16 * WGN);
+  constexpr int PX = BM / 8, PW = BN / 8;
+  constexpr int GX = PX / NW, GW = PW / NW;
+  static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
+  constexpr int STAGE = (BM + BN) * ROWB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  int tile, slice;
+  splitk_block_of(blockIdx.x, tiles, S, tile, slice);
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int KT_all = (K + BK - 1) / BK;
+  const int kt0 = slice * kt_per;
+  const int kt1 = kt0 + kt_per < KT_all ? kt0 + kt_per : KT_all;
+
+  const int lrow = lane >> 3, slot = lane & 7;
+  const bf16* xsrc[GX]; int xk[GX];
+  const bf16* wsrc[GW]; int wk[GW];
+#pragma unroll
+  for (int t = 0; t < GX; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gm = m0 + R; gm = gm < M ? gm : M - 1;
+    xsrc[t] = X + (int64_t)gm * ldx + g * 8;
+    xk[t] = g * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < GW; ++t) {
+    const int R = (wave + NW * t) * 8 + lrow;
+    const int g = slot ^ ((R >> 1) & 7);
+    int gn = n0 + R; gn = gn < N ? gn : N - 1;
+    wsrc[t] = W + (int64_t)gn * ldw + g * 8;
+    wk[t] = g * 8;
+  }
+  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
+  const bool ktail = (K % BK) != 0;
+  auto stage = [&](int kt, int buf) {
+    char* xb = smem + buf * STAGE;
+    char* wb = xb + BM * ROWB;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int t = 0; t < GX; ++t) {
+      const bf16* s = xsrc[t] + k0;
+      if (ktail && k0 + xk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < GW; ++t) {
+      const bf16* s = wsrc[t] + k0;
+      if (ktail && k0 + wk[t] >= K) s = zero;
+      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int r16 = lane & 15, kq = lane >> 4, fsw = (r16 >> 1) & 7;
+  unsigned xa[2], wa[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int coff = (((ks * 4 + kq) ^ fsw) << 4);
+    xa[ks] = vy_lds_addr(smem) + (wm * 16 * TM + r16) * ROWB + coff;
+    wa[ks] = vy_lds_addr(smem) + BM * ROWB + (wn * 16 * TN + r16) * ROWB + coff;
+  }
+  bf16x8 wf[2][TN], xf[2][TM];
+  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; w_[i] = vy_lds_read128_off<i * 16 * ROWB>(wbase); });
+    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; x_[j] = vy_lds_read128_off<j * 16 * ROWB>(xbase); });
+  };
+  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) vy_tie(w_[i]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) vy_tie(x_[j]);
+  };
+  auto mma = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_[i], x_[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  if (kt0 < kt1) {   // (workgroup-uniform; an empty slice stores zeros)
+    stage(kt0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(wa[0], xa[0], wf[0], xf[0]);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
+      const unsigned boff = cur * STAGE;
+      read_frags(wa[1] + boff, xa[1] + boff, wf[1], xf[1]);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+      tie_frags(wf[0], xf[0]);
+      mma(wf[0], xf[0]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tie_frags(wf[1], xf[1]);
+      mma(wf[1], xf[1]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 1 < kt1) read_frags(wa[0] + (STAGE - boff), xa[0] + (STAGE - boff), wf[0], xf[0]);
+    }
+  }
+  // the accumulators as they sit in the registers: [slice][tile][wave][i][j][lane] f32x4
+  f32x4* out = reinterpret_cast<f32x4*>(ws) + (((int64_t)slice * tiles + tile) * NW + wave) * (TN * TM * 64) + lane;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) out[(i * TM + j) * 64] = acc[i][j];
+}
+
+template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_splitk_finish_kernel(
+    const float* __restrict__ ws, int M, int N, int tiles_n, int tiles, int S, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
+  constexpr int NW = WGM * WGN;
+  constexpr int TM = BM / (16 * WGM), TN = BN / (16 * WGN);
+  __shared__ __attribute__((aligned(16))) char smem[epi_lds_bytes(BM, BN, EPI, 1)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x;
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  f32x4 acc[TN][TM];
+  const f32x4* in = reinterpret_cast<const f32x4*>(ws) + ((int64_t)tile * NW + wave) * (TN * TM * 64) + lane;
+  const int64_t slice_stride = (int64_t)tiles * NW * (TN * TM * 64);
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = in[(i * TM + j) * 64];
+  for (int s = 1; s < S; ++s) {
+    const f32x4* p = in + s * slice_stride;
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const f32x4 v = p[(i * TM + j) * 64];
+        acc[i][j] = acc[i][j] + v;
+      }
+  }
+  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD, 1, true, true>(acc, smem, tile_m * BM, tile_n * BN, M, N, ep, eq);
+}
+
+// Workspaces for the split-K launches, registered per stream by the caller (the library never allocates device memory):
+// vy_workspace_set(stream, ptr, bytes).  Launches on a stream without one simply do not split.
+struct WsEntry { hipStream_t st; void* p; int64_t bytes; };
+WsEntry g_ws[16];
+int g_ws_n = 0;
+std::mutex g_ws_mu;
+inline float* splitk_ws(hipStream_t st, int64_t need) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (int i = 0; i < g_ws_n; ++i)
+    if (g_ws[i].st == st) return g_ws[i].bytes >= need ? (float*)g_ws[i].p : nullptr;
+  return nullptr;
+}
+// slices for a tile grid: ~two workgroups per CU, at least six 64-deep stages per slice
+inline int splitk_slices(int64_t tiles, int KT) {
+  static const int on = [] { const char* e = getenv("VY_SPLITK"); return e ? atoi(e) : 1; }();
+  static const int target = [] { const char* e = getenv("VY_SPLITK_WGS"); return e ? atoi(e) : 448; }();
+  if (!on || tiles >= 300 || g_chains != 1) return 1;
+  int S = (int)((target + tiles / 2) / tiles);
+  if (S > KT / 6) S = KT / 6;
+  if (S > 16) S = 16;
+  if (S < 2) return 1;
+  int p2 = 2;
+  while (p2 * 2 <= S) p2 *= 2;   // a power of two: one slice per group of XCDs (splitk_block_of)
+  S = p2;
+  const int per = (KT + S - 1) / S;
+  return (KT + per - 1) / per;   // no empty slice
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2566,7 +2775,17 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     // (M = 2112 rows of a captioning decoder x N = 768: 36 tiles of 256 x 192, 102 of 128 x 128)
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
     static const int mid16 = [] { const char* e = getenv("VY_GEMM_MID16"); return e ? atoi(e) : 1; }();
-    if (mid16)
+    const int KT = (int)vy_cdiv(K, 64);
+    const int tiles = tm * tn;
+    const int S = mid16 ? splitk_slices(tiles, KT) : 1;
+    float* ws = S > 1 ? splitk_ws(st, (int64_t)S * tiles * 128 * 128 * 4) : nullptr;
+    if (ws) {
+      const int per = (KT + S - 1) / S;
+      hipLaunchKernelGGL((gemm_nt_bf16_m16_splitk_kernel<128, 128, 2, 2>), dim3(tiles * S), dim3(256), 0, st, X, ldx, W, ldw,
+                         (int)M, (int)N, (int)K, tn, tiles, S, per, ws);
+      hipLaunchKernelGGL((gemm_splitk_finish_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tiles), dim3(256), 0, st, ws,
+                         (int)M, (int)N, tn, tiles, S, ep, eq);
+    } else if (mid16)
       hipLaunchKernelGGL((gemm_nt_bf16_m16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
     else
@@ -2861,6 +3080,21 @@ extern "C" int vy_qkv_rope_fwd(const void* x, int64_t ldx, const void* w, int64_
 int64_t vy_splitk_ws_floats(int64_t N) { return 8 * 32 * N; }
 
 extern "C" int vy_debug_set_gemm_variant(int v) { g_gemm_variant = v; return 0; }
+extern "C" int vy_workspace_set(void* stream, void* ws, int64_t bytes) {
+  if (bytes < 0 || (ws && ((uintptr_t)ws & 255))) VY_FAIL(VY_ERR_ARG, "vy_workspace_set: bad workspace (256-byte aligned, bytes >= 0)");
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < g_ws_n; ++i)
+    if (g_ws[i].st == st) {
+      if (ws && bytes) { g_ws[i].p = ws; g_ws[i].bytes = bytes; }
+      else { g_ws[i] = g_ws[g_ws_n - 1]; --g_ws_n; }
+      return VY_OK;
+    }
+  if (!ws || !bytes) return VY_OK;
+  if (g_ws_n == 16) VY_FAIL(VY_ERR_ARG, "vy_workspace_set: more than 16 streams hold a workspace");
+  g_ws[g_ws_n++] = WsEntry{st, ws, bytes};
+  return VY_OK;
+}
 extern "C" int vy_set_concurrent_chains(int n) {
   if (n < 1 || n > 8) VY_FAIL(VY_ERR_ARG, "vy_set_concurrent_chains: n = %d (1..8)", n);
   g_chains = n;

@@ -117,6 +117,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_WS = {}
+_WS_BYTES = 32 << 20
+
+
+def _mid_ws(rows: int) -> None:
+    """Mid-size GEMMs (32 < rows <= 4096) split K over workgroups and need scratch for their fp32 partial tiles
+    (vy_workspace_set: one buffer per stream, registered once; the library never allocates device memory)."""
+    if rows <= 32 or rows > 4096 or _Lanes.active:
+        return
+    st = torch.cuda.current_stream()
+    key = (st.device_index, st.cuda_stream)
+    if key not in _WS:
+        buf = torch.empty(_WS_BYTES, dtype=torch.uint8, device=torch.device("cuda", st.device_index))
+        call("vy_workspace_set", st.cuda_stream, buf.data_ptr(), _WS_BYTES)
+        _WS[key] = buf
+
+
 def _at(t: Optional[Tensor], first: int):
     """data pointer of t[first:] (None stays None)."""
     if t is None:
@@ -175,10 +192,12 @@ def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = _lib.
     if dropout is not None and dropout[0] > 0.0:
         # (the mask is a function of the global row index: this launch is never split over the lanes)
         assert act == _lib.ACT_NONE and p2 is None
+        _mid_ws(M)
         call("vy_linear_dropout_fwd", x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
              _ptr(r2), r2.stride(0) if r2 is not None else 0, y2.data_ptr(), y2.stride(0), M, N, K,
              float(dropout[0]), int(dropout[1]), int(dropout[2]), dtype_code(x.dtype), _stream())
         return ret
+    _mid_ws(M)
     whole = _Lanes.active and (x2.data_ptr() != x.data_ptr() or (r2 is not None and r2.data_ptr() != residual.data_ptr()))
     for m0, m, st in ([(0, M, _stream())] if whole else _lane_plan(rows=M, keep=(x2, r2, y2, p2, w, bias))):
         call("vy_linear_fwd", _at(x2, m0), x2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias),
@@ -197,6 +216,7 @@ def qkv_rope(x: Tensor, w_packed: Tensor, b_packed: Optional[Tensor], h: int, hk
     x2 = _rows(x)
     for t in (q, k, v):
         assert t.stride(3) == 1
+    _mid_ws(B * L)
     whole = _Lanes.active and (x2.data_ptr() != x.data_ptr() or L != _Lanes.L)
     for b0, nb, st in ([(0, B, _stream())] if whole else _lane_plan(batches=B, keep=(x2, q, k, v, w_packed, b_packed))):
         call("vy_qkv_rope_fwd", _at(x2, b0 * L), x2.stride(0), w_packed.data_ptr(), w_packed.stride(0),
@@ -319,6 +339,7 @@ def linear_dgrad(dy: Tensor, wt: Tensor, pre: Optional[Tensor] = None, act: int 
     p2 = _rows(pre) if pre is not None else None
     a2 = _rows(add_to) if add_to is not None else None
     b2 = _rows(add_to2) if add_to2 is not None else None
+    _mid_ws(M)
     call("vy_linear_dgrad", d2.data_ptr(), d2.stride(0), wt.data_ptr(), wt.stride(0), _ptr(p2),
          p2.stride(0) if p2 is not None else 0, act, _ptr(a2), a2.stride(0) if a2 is not None else 0,
          _ptr(b2), b2.stride(0) if b2 is not None else 0,
