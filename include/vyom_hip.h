@@ -59,7 +59,7 @@ int vy_set_concurrent_chains(int n);
 
 /* Scratch for the launches on `stream` (the library never allocates device memory): mid-size GEMMs (32 < M <= ~2304 rows,
  * fewer than 300 tiles of 128 x 128) split K over workgroups and keep fp32 partial tiles here between their two launches
- * -- 64 KiB per (tile, slice), at most 512 of them = 32 MiB.  One workspace per stream (launches on one stream are
+ * -- 64 KiB per (tile, slice), the widest launch (16 slices of 16 tiles of 320 x 128) needs 42 MiB; the host layer registers 64 MiB.  One workspace per stream (launches on one stream are
  * ordered, so they can share it); ws = NULL or bytes = 0 removes the entry.  Without a workspace such GEMMs run unsplit:
  * results are the same up to the fp32 summation order over K. */
 int vy_workspace_set(void* stream, void* ws, int64_t bytes);

@@ -1367,34 +1367,45 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_m16_splitk_kernel
     for (int j = 0; j < TM; ++j) out[(i * TM + j) * 64] = acc[i][j];
 }
 
+// One 64-thread workgroup per 16-ROW BLOCK of a wave's sub-tile (16 x SN outputs, 4 accumulator quads per lane): all S x 4
+// partial reads of a lane are requested at once -- ONE round trip to the partials other XCDs left in HBM / MALL, where a
+// whole-sub-tile finish walked S dependent trips (11 us per launch) -- and 16 x as many workgroups share the launch.  The
+// block goes through the staged epilogue as a tile of its own (rows of SN = 64 bf16 = one 128-byte line each).
 template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_splitk_finish_kernel(
+__global__ __launch_bounds__(64) void gemm_splitk_finish_kernel(
     const float* __restrict__ ws, int M, int N, int tiles_n, int tiles, int S, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
   constexpr int NW = WGM * WGN;
   constexpr int TM = BM / (16 * WGM), TN = BN / (16 * WGN);
-  __shared__ __attribute__((aligned(16))) char smem[epi_lds_bytes(BM, BN, EPI, 1)];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile = blockIdx.x;
+  constexpr int SM = BM / WGM, SN = BN / WGN;   // the wave's sub-tile
+  constexpr int SMAX = 16;
+  __shared__ __attribute__((aligned(16))) char smem[epi_lds_bytes(16, SN, EPI, 1)];
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x / (NW * TM);
+  const int rem = blockIdx.x - tile * (NW * TM);
+  const int wave = rem / TM, j = rem - wave * TM;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
   const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
-  f32x4 acc[TN][TM];
-  const f32x4* in = reinterpret_cast<const f32x4*>(ws) + ((int64_t)tile * NW + wave) * (TN * TM * 64) + lane;
+  const int m0 = tile_m * BM + wm * SM + j * 16, n0 = tile_n * BN + wn * SN;
+  if (m0 >= M || n0 >= N) return;   // (workgroup-uniform)
+  const f32x4* in = reinterpret_cast<const f32x4*>(ws) + ((int64_t)tile * NW + wave) * (TN * TM * 64) + j * 64 + lane;
   const int64_t slice_stride = (int64_t)tiles * NW * (TN * TM * 64);
+  f32x4 part[SMAX][TN];
 #pragma unroll
-  for (int i = 0; i < TN; ++i)
+  for (int sidx = 0; sidx < SMAX; ++sidx)
+    if (sidx < S) {
 #pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = in[(i * TM + j) * 64];
-  for (int s = 1; s < S; ++s) {
-    const f32x4* p = in + s * slice_stride;
+      for (int i = 0; i < TN; ++i) part[sidx][i] = in[sidx * slice_stride + (int64_t)i * TM * 64];
+    }
+  f32x4 acc[TN][1];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+  for (int i = 0; i < TN; ++i) acc[i][0] = part[0][i];
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const f32x4 v = p[(i * TM + j) * 64];
-        acc[i][j] = acc[i][j] + v;
-      }
-  }
-  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD, 1, true, true>(acc, smem, tile_m * BM, tile_n * BN, M, N, ep, eq);
+  for (int sidx = 1; sidx < SMAX; ++sidx)
+    if (sidx < S) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) acc[i][0] = acc[i][0] + part[sidx][i];   // slice order: deterministic
+    }
+  gemm_epilogue<16, SN, 1, 1, EPI, ACT, GRAD, 1, true, true>(acc, smem, m0, n0, M, N, ep, eq);
 }
 
 // Workspaces for the split-K launches, registered per stream by the caller (the library never allocates device memory):
@@ -1409,13 +1420,14 @@ inline float* splitk_ws(hipStream_t st, int64_t need) {
     if (g_ws[i].st == st) return g_ws[i].bytes >= need ? (float*)g_ws[i].p : nullptr;
   return nullptr;
 }
-// slices for a tile grid: ~two workgroups per CU, at least six 64-deep stages per slice
-inline int splitk_slices(int64_t tiles, int KT) {
+// slices for a tile grid: `target` workgroups in all (two per CU for the 128 x 128 tiles, one for the all-rows tiles), at least
+// four 64-deep stages per slice
+inline int splitk_slices(int64_t tiles, int KT, int target) {
   static const int on = [] { const char* e = getenv("VY_SPLITK"); return e ? atoi(e) : 1; }();
-  static const int target = [] { const char* e = getenv("VY_SPLITK_WGS"); return e ? atoi(e) : 448; }();
-  if (!on || tiles >= 300 || g_chains != 1) return 1;
+  static const int min_stages = [] { const char* e = getenv("VY_SPLITK_MIN_STAGES"); return e ? atoi(e) : 4; }();
+  if (!on || tiles * 3 >= target * 2 || g_chains != 1) return 1;
   int S = (int)((target + tiles / 2) / tiles);
-  if (S > KT / 6) S = KT / 6;
+  if (S > KT / min_stages) S = KT / min_stages;
   if (S > 16) S = 16;
   if (S < 2) return 1;
   int p2 = 2;
@@ -1423,6 +1435,29 @@ inline int splitk_slices(int64_t tiles, int KT) {
   S = p2;
   const int per = (KT + S - 1) / S;
   return (KT + per - 1) / per;   // no empty slice
+}
+
+// mid-size M launch on BM x BN tiles: split over K when the tile grid leaves CUs idle and the stream has a workspace
+template <int BM, int BN, int WGM, int WGN, int EPI, int ACT, bool GRAD>
+void launch_mid(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t M, int64_t N, int64_t K,
+                const EpiPlain<bf16>& ep, const EpiQkv<bf16>& eq, hipStream_t st, int target, int rot) {
+  constexpr int NT = 64 * WGM * WGN;
+  const int tn = (int)vy_cdiv(N, BN), tm = (int)vy_cdiv(M, BM);
+  const int KT = (int)vy_cdiv(K, 64);
+  const int tiles = tm * tn;
+  const int S = splitk_slices(tiles, KT, target);
+  float* ws = S > 1 ? splitk_ws(st, (int64_t)S * tiles * BM * BN * 4) : nullptr;
+  if (ws) {
+    const int per = (KT + S - 1) / S;
+    hipLaunchKernelGGL((gemm_nt_bf16_m16_splitk_kernel<BM, BN, WGM, WGN>), dim3(tiles * S), dim3(NT), 0, st, X, ldx, W, ldw,
+                       (int)M, (int)N, (int)K, tn, tiles, S, per, ws);
+    constexpr int TMB = BM / (16 * WGM);
+    hipLaunchKernelGGL((gemm_splitk_finish_kernel<BM, BN, WGM, WGN, EPI, ACT, GRAD>), dim3(tiles * WGM * WGN * TMB), dim3(64), 0,
+                       st, ws, (int)M, (int)N, tn, tiles, S, ep, eq);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_bf16_m16_kernel<BM, BN, WGM, WGN, EPI, ACT, GRAD>), dim3(tiles), dim3(NT), 0,
+                       st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2775,19 +2810,15 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     // (M = 2112 rows of a captioning decoder x N = 768: 36 tiles of 256 x 192, 102 of 128 x 128)
     const int tn = (int)vy_cdiv(N, 128), tm = (int)vy_cdiv(M, 128);
     static const int mid16 = [] { const char* e = getenv("VY_GEMM_MID16"); return e ? atoi(e) : 1; }();
-    const int KT = (int)vy_cdiv(K, 64);
-    const int tiles = tm * tn;
-    const int S = mid16 ? splitk_slices(tiles, KT) : 1;
-    float* ws = S > 1 ? splitk_ws(st, (int64_t)S * tiles * 128 * 128 * 4) : nullptr;
-    if (ws) {
-      const int per = (KT + S - 1) / S;
-      hipLaunchKernelGGL((gemm_nt_bf16_m16_splitk_kernel<128, 128, 2, 2>), dim3(tiles * S), dim3(256), 0, st, X, ldx, W, ldw,
-                         (int)M, (int)N, (int)K, tn, tiles, S, per, ws);
-      hipLaunchKernelGGL((gemm_splitk_finish_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tiles), dim3(256), 0, st, ws,
-                         (int)M, (int)N, tn, tiles, S, ep, eq);
+    // 128 < M <= 320 (a 256-patch vision tower, a 264-row PaliGemma prefill): ONE row tile holds every row, so each weight
+    // element crosses L2 -> LDS once per launch and the 8 rows past 256 do not cost a third row of 128 x 128 tiles
+    // (all-rows tiles of 256 or 320 x 128, 8 waves, one workgroup per CU; VY_GEMM_ROWS=0: the 128 x 128 tiles)
+    static const int rows_on = [] { const char* e = getenv("VY_GEMM_ROWS"); return e ? atoi(e) : 1; }();
+    if (mid16 && rows_on && M > 128 && M <= 320) {
+      if (M <= 256) launch_mid<256, 128, 4, 2, EPI, ACT, GRAD>(X, ldx, W, ldw, M, N, K, ep, eq, st, 256, rot);
+      else launch_mid<320, 128, 4, 2, EPI, ACT, GRAD>(X, ldx, W, ldw, M, N, K, ep, eq, st, 256, rot);
     } else if (mid16)
-      hipLaunchKernelGGL((gemm_nt_bf16_m16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
+      launch_mid<128, 128, 2, 2, EPI, ACT, GRAD>(X, ldx, W, ldw, M, N, K, ep, eq, st, 448, rot);
     else
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
@@ -3091,7 +3122,10 @@ extern "C" int vy_workspace_set(void* stream, void* ws, int64_t bytes) {
       return VY_OK;
     }
   if (!ws || !bytes) return VY_OK;
-  if (g_ws_n == 16) VY_FAIL(VY_ERR_ARG, "vy_workspace_set: more than 16 streams hold a workspace");
+  if (g_ws_n == 16) {   // full: the oldest entry goes (its stream's later launches run unsplit -- speed only)
+    for (int i = 1; i < 16; ++i) g_ws[i - 1] = g_ws[i];
+    --g_ws_n;
+  }
   g_ws[g_ws_n++] = WsEntry{st, ws, bytes};
   return VY_OK;
 }

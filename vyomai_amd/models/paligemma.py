@@ -11,6 +11,8 @@ Inference only (config 5 of BASELINE.json is KV-cache decode).
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
@@ -267,9 +269,16 @@ class PaliGemmaForConditionalGeneration(nn.Module):
     def lm_head(self, hidden: torch.Tensor) -> torch.Tensor:
         return ops.linear(hidden, self.embed_tokens.weight)  # tied (GemmaForCausalLM.tie_weights)
 
+    def _embed_scale(self, like: torch.Tensor) -> torch.Tensor:
+        """sqrt(d) as a tensor of the activations' dtype (the notebook's `normalizer`, cell 13: rounded to bf16 BEFORE the
+        multiply) -- kept on the device, so that no host-to-device copy sits inside a prefill (a hipGraph cannot hold one)."""
+        c = getattr(self, "_scale_cache", None)
+        if c is None or c.dtype != like.dtype or c.device != like.device:
+            c = self._scale_cache = torch.tensor(self.shape.text.hidden_size ** 0.5, dtype=like.dtype, device=like.device)
+        return c
+
     def _decoder(self, hidden, start_pos, caches):
-        t = self.shape.text
-        hidden = hidden * torch.tensor(t.hidden_size ** 0.5, dtype=hidden.dtype, device=hidden.device)
+        hidden = hidden * self._embed_scale(hidden)
         for i, layer in enumerate(self.layers):
             hidden = layer(hidden, self.rope, start_pos, causal=False, cache=None if caches is None else caches[i],
                            pos_offset=self.ROPE_OFFSET)
@@ -289,31 +298,78 @@ class PaliGemmaForConditionalGeneration(nn.Module):
         hidden = torch.cat([self.image_features(pixel_values), self.embed_tokens(input_ids)], dim=1)
         return self._decoder(hidden, 0, caches)
 
+    # ---- generation state: static caches, the captured prefill, the decode plan ----------------------------------
+    def _weights_key(self):
+        return tuple(p._version for p in self.parameters()) + (self.embed_tokens.weight.data_ptr(),)
+
+    def _generation_state(self, pixel_values, input_ids, max_cache_len: int):
+        """Everything of generate() that does not depend on the VALUES of the inputs, built once per (batch, prompt length,
+        cache length) and kept while the weights are untouched: the K/V buffers (slots past the prefix are written before
+        they are read, so they need no clearing between calls), the decode plan over them (its RMSNorm-folded weight copies
+        alone cost ~5 ms to build) and the prefill as ONE hipGraph -- vision tower, projector, the 264-row language-model
+        pass and the vocabulary product of the last position are ~450 launches that the host needs ~9 ms to enqueue one
+        by one, longer than the GPU needs to run them (VY_PREFILL_GRAPH=0: eager launches)."""
+        t = self.shape.text
+        dev, dt = pixel_values.device, self.embed_tokens.weight.dtype
+        B, T = input_ids.shape
+        key = (B, T, tuple(pixel_values.shape), max_cache_len, dt, dev)
+        st = getattr(self, "_gen_state", None)
+        wkey = self._weights_key()
+        if st is not None and st["key"] == key and st["wkey"] == wkey:
+            return st
+        st = {"key": key, "wkey": wkey, "graph": None, "plan": None}
+        st["caches"] = [(torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev),
+                         torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev))
+                        for _ in self.layers]
+        st["no_stop"] = torch.tensor([-1], dtype=torch.long, device=dev)
+        self._gen_state = st
+        return st
+
+    def _prefill_first_logits(self, pixel_values, input_ids, caches) -> torch.Tensor:
+        hidden = torch.cat([self.image_features(pixel_values), self.embed_tokens(input_ids)], dim=1)
+        out = self._decoder(hidden, 0, caches)
+        return self.lm_head(out[:, -1:, :])[:, -1]
+
+    def _run_prefill(self, st, pixel_values, input_ids) -> torch.Tensor:
+        if os.environ.get("VY_PREFILL_GRAPH", "1") == "0":
+            return self._prefill_first_logits(pixel_values, input_ids, st["caches"])
+        if st["graph"] is None:
+            st["px"], st["ids"] = pixel_values.clone(), input_ids.clone()
+            # eager once (packs the sibling projections, warms the allocator), then record
+            self._prefill_first_logits(st["px"], st["ids"], st["caches"])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["first"] = self._prefill_first_logits(st["px"], st["ids"], st["caches"])
+            st["graph"] = g
+        st["px"].copy_(pixel_values)
+        st["ids"].copy_(input_ids)
+        st["graph"].replay()
+        return st["first"]
+
     @torch.no_grad()
     def generate(self, pixel_values: torch.Tensor, input_ids: torch.Tensor, max_new_tokens: int = 64,
                  max_cache_len: int = 384) -> torch.Tensor:
         t = self.shape.text
-        dev, dt = pixel_values.device, self.embed_tokens.weight.dtype
+        dev = pixel_values.device
         B = input_ids.shape[0]
-        hidden = torch.cat([self.image_features(pixel_values), self.embed_tokens(input_ids)], dim=1)
-        if hidden.shape[1] + max_new_tokens - 1 > max_cache_len:
-            raise ValueError(f"{hidden.shape[1]} prefix tokens + {max_new_tokens} new tokens exceed max_cache_len={max_cache_len}")
-        caches = [(torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev),
-                   torch.zeros(B, t.num_key_value_heads, max_cache_len, t.head_dim, dtype=dt, device=dev))
-                  for _ in self.layers]
-        pos = hidden.shape[1]
-        out = self._decoder(hidden, 0, caches)
+        n_img = self.vision_tower.num_patches
+        pos = n_img + input_ids.shape[1]
+        if pos + max_new_tokens - 1 > max_cache_len:
+            raise ValueError(f"{pos} prefix tokens + {max_new_tokens} new tokens exceed max_cache_len={max_cache_len}")
+        st = self._generation_state(pixel_values, input_ids, max_cache_len)
+        first = self._run_prefill(st, pixel_values, input_ids)
         # greedy loop: the first token comes from the prefill; every later one is ONE native call through the
         # stack (vy_gemma_decoder_step) plus one for the pick (vy_greedy_step) -- no per-layer Python
         tokens = torch.zeros((B, max_new_tokens), dtype=torch.long, device=dev)
         done = torch.zeros(B, dtype=torch.bool, device=dev)       # (the notebook's loop has no early stop)
-        no_stop = torch.tensor([-1], dtype=torch.long, device=dev)
-        first = self.lm_head(out[:, -1:, :])[:, -1]
+        no_stop = st["no_stop"]
         ops.greedy_step_(first, tokens, 0, None, no_stop, done)
         if max_new_tokens > 1:
-            from ..decode_plan import GemmaDecodePlan
-            plan = GemmaDecodePlan(self, caches, B)
-            scale = torch.tensor(t.hidden_size ** 0.5, dtype=dt, device=dev)
+            if st["plan"] is None:
+                from ..decode_plan import GemmaDecodePlan
+                st["plan"] = GemmaDecodePlan(self, st["caches"], B)
+            plan = st["plan"]
+            scale = self._embed_scale(self.embed_tokens.weight)
             for i in range(1, max_new_tokens):
                 x = self.embed_tokens(tokens[:, i - 1]) * scale
                 ops.greedy_step_(plan.step(x.contiguous(), pos), tokens, i, None, no_stop, done)

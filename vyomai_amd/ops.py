@@ -118,7 +118,7 @@ def _stream() -> int:
 
 
 _WS = {}
-_WS_BYTES = 32 << 20
+_WS_BYTES = 64 << 20
 
 
 def _mid_ws(rows: int) -> None:
