@@ -1421,10 +1421,11 @@ inline float* splitk_ws(hipStream_t st, int64_t need) {
   return nullptr;
 }
 // slices for a tile grid: `target` workgroups in all (two per CU for the 128 x 128 tiles, one for the all-rows tiles), at least
-// four 64-deep stages per slice
+// two 64-deep stages per slice
 inline int splitk_slices(int64_t tiles, int KT, int target) {
   static const int on = [] { const char* e = getenv("VY_SPLITK"); return e ? atoi(e) : 1; }();
-  static const int min_stages = [] { const char* e = getenv("VY_SPLITK_MIN_STAGES"); return e ? atoi(e) : 4; }();
+  // (measured, same box: 2 stages per slice at least -- configs[4] prefill 7.09 -> 6.88 ms, configs[3] step 19.1 -> 18.5 ms against 4)
+  static const int min_stages = [] { const char* e = getenv("VY_SPLITK_MIN_STAGES"); return e ? atoi(e) : 2; }();
   if (!on || tiles * 3 >= target * 2 || g_chains != 1) return 1;
   int S = (int)((target + tiles / 2) / tiles);
   if (S > KT / min_stages) S = KT / min_stages;
