@@ -57,6 +57,8 @@ struct DecGemmArgs {
   const float* cos_tab; const float* sin_tab; const int* pos_dev;
   int pos0, nq, nkv, rope;
   int wt;                              // write-through stores
+  const bf16* residual; int ldr;       // DEC_STORE: y = bf16(act(x W^T + b) + residual)
+  const bf16* ln_g; const bf16* ln_b; float ln_eps;   // LNP kernels: the rows of X are LayerNorm'ed on the way in
 };
 
 // sum over the 64 lanes, result in every lane: four DPP rotations inside each row of 16 lanes, then the two
@@ -70,6 +72,16 @@ __device__ __forceinline__ float dec_row16_sum(float v) {
 }
 __device__ __forceinline__ float dec_wave_sum(float v) {
   v = dec_row16_sum(v);
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
+  const unsigned w = __builtin_bit_cast(unsigned, v);
+  auto s32 = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __builtin_bit_cast(float, (unsigned)s32[0]) + __builtin_bit_cast(float, (unsigned)s32[1]);
+}
+// sum over the four 16-lane rows of the wave at each position inside a row (lanes l, l ^ 16, l ^ 32, l ^ 48), in every
+// lane: the two half-swaps of dec_wave_sum without the in-row rotations
+__device__ __forceinline__ float dec_rows_sum(float v) {
   const unsigned u = __builtin_bit_cast(unsigned, v);
   auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
   v = __builtin_bit_cast(float, (unsigned)s16[0]) + __builtin_bit_cast(float, (unsigned)s16[1]);
@@ -121,9 +133,16 @@ __device__ __forceinline__ float dec_swap32(float v, bool upper) {
 // a workgroup takes columns {d0 .. d0+7} and {d0+32 .. d0+39} of one 64-wide head: a rotary pair sits in lanes l
 // and l ^ 32.  Same arithmetic as gemm_skinny16_bf16_kernel (vy_gemm.hip).
 // ------------------------------------------------------------------------------------------
-template <int EPI, int ACT, int U, bool DBG>
+// LNP: the rows of X are normalised on the way in -- y = act(LayerNorm(x) W^T + b) without a LayerNorm launch in front.
+// A workgroup holds every element of all 32 rows anyway (its four waves split K), so the row statistics are two
+// reductions over values already in registers: over the 4 lane rows of a wave (permlane swaps), then over the 4 waves
+// through LDS (one barrier each: mean, then the sum of squared deviations -- the two-pass form of dec_finish_ln_kernel,
+// same rsqrt refinement, the normalised value rounded to bf16 exactly where that kernel stores it).  The launch this
+// saves is a ~4.3 us link of the step's dependent chain; every workgroup redoes the statistics (25 k elements: noise).
+template <int EPI, int ACT, int U, bool DBG, bool LNP = false>
 __global__ __launch_bounds__(256) void dec_gemm16_kernel(const DecGemmArgs p, const DecDbg dbg) {
   __shared__ float red[3][8][64];
+  __shared__ float lnred[2][4][32];
   unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   DEC_STAMP(0)
   if constexpr (DBG) { asm volatile("" ::"s"(p.M), "s"(p.ldw)); }
@@ -150,11 +169,23 @@ __global__ __launch_bounds__(256) void dec_gemm16_kernel(const DecGemmArgs p, co
   bf16x4 bias4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
   if (EPI != DEC_PART && p.bias) bias4 = *reinterpret_cast<const bf16x4*>(p.bias + nq0);
   bf16x8 a[U], b0[U], b1[U];
+  bf16x8 lg[LNP ? U : 1], lb[LNP ? U : 1];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     a[u] = *reinterpret_cast<const bf16x8*>(wp + 128 * u);
     b0[u] = *reinterpret_cast<const bf16x8*>(xp0 + 128 * u);
     b1[u] = *reinterpret_cast<const bf16x8*>(xp1 + 128 * u);
+    if constexpr (LNP) {
+      lg[u] = *reinterpret_cast<const bf16x8*>(p.ln_g + kbase + 128 * u);
+      lb[u] = *reinterpret_cast<const bf16x8*>(p.ln_b + kbase + 128 * u);
+    }
+  }
+  bf16x4 res0 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, res1 = res0;
+  if constexpr (EPI == DEC_STORE) {
+    if (p.residual) {   // (workgroup-uniform; requested with everything else, used by wave 0 at the very end)
+      res0 = *reinterpret_cast<const bf16x4*>(p.residual + (long long)m0 * p.ldr + nq0);
+      res1 = *reinterpret_cast<const bf16x4*>(p.residual + (long long)m1 * p.ldr + nq0);
+    }
   }
   int pos = 0;
   f32x4 cos4 = {1.f, 1.f, 1.f, 1.f}, sin4 = {0.f, 0.f, 0.f, 0.f};
@@ -168,6 +199,43 @@ __global__ __launch_bounds__(256) void dec_gemm16_kernel(const DecGemmArgs p, co
     }
   }
   DEC_STAMP(1)
+  if constexpr (LNP) {
+    const float inv_n = 1.0f / (float)(128 * U);   // K = 4 waves x U k-steps x 32
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s0 += (float)b0[u][e]; s1 += (float)b1[u][e]; }
+    s0 = dec_rows_sum(s0); s1 = dec_rows_sum(s1);
+    if (kq == 0) { lnred[0][wave][r16] = s0; lnred[0][wave][16 + r16] = s1; }
+    __syncthreads();
+    const float mean0 = (lnred[0][0][r16] + lnred[0][1][r16] + lnred[0][2][r16] + lnred[0][3][r16]) * inv_n;
+    const float mean1 = (lnred[0][0][16 + r16] + lnred[0][1][16 + r16] + lnred[0][2][16 + r16] + lnred[0][3][16 + r16]) * inv_n;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d0 = (float)b0[u][e] - mean0, d1 = (float)b1[u][e] - mean1;
+        q0 += d0 * d0; q1 += d1 * d1;
+      }
+    q0 = dec_rows_sum(q0); q1 = dec_rows_sum(q1);
+    if (kq == 0) { lnred[1][wave][r16] = q0; lnred[1][wave][16 + r16] = q1; }
+    __syncthreads();
+    const float var0 = (lnred[1][0][r16] + lnred[1][1][r16] + lnred[1][2][r16] + lnred[1][3][r16]) * inv_n + p.ln_eps;
+    const float var1 = (lnred[1][0][16 + r16] + lnred[1][1][16 + r16] + lnred[1][2][16 + r16] + lnred[1][3][16 + r16]) * inv_n + p.ln_eps;
+    float r0 = rsqrtf(var0), r1 = rsqrtf(var1);
+    r0 = r0 * (1.5f - 0.5f * var0 * r0 * r0);
+    r1 = r1 * (1.5f - 0.5f * var1 * r1 * r1);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = (float)lg[u][e], be = (float)lb[u][e];
+        b0[u][e] = (bf16)(((float)b0[u][e] - mean0) * r0 * g + be);
+        b1[u][e] = (bf16)(((float)b1[u][e] - mean1) * r1 * g + be);
+      }
+  }
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -196,8 +264,9 @@ __global__ __launch_bounds__(256) void dec_gemm16_kernel(const DecGemmArgs p, co
     bf16x4 o0, o1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      o0[i] = (bf16)vy_act_fwd_fast<ACT>(acc0[i] + (float)bias4[i]);
-      o1[i] = (bf16)vy_act_fwd_fast<ACT>(acc1[i] + (float)bias4[i]);
+      // (+ residual in fp32, one rounding: the value dec_finish_ln_kernel normalises)
+      o0[i] = (bf16)(vy_act_fwd_fast<ACT>(acc0[i] + (float)bias4[i]) + (float)res0[i]);
+      o1[i] = (bf16)(vy_act_fwd_fast<ACT>(acc1[i] + (float)bias4[i]) + (float)res1[i]);
     }
     bf16* dst = p.y + (long long)r16 * p.ldy + nq0;
     if (r16 < p.M) dec_store(dst, o0, p.wt);
@@ -393,6 +462,16 @@ int dec_gemm_go(DecGemmArgs a, int K, int chunks, hipStream_t st) {
   a.wt = dec_wt();
   const int u4 = K / chunks / 128;   // k-steps per wave
   const dim3 grid((unsigned)(a.N / 16), (unsigned)chunks), block(256);
+  if constexpr (EPI == DEC_STORE) {
+    if (a.ln_g) {   // LayerNorm prologue: the workgroup must hold whole rows (one K chunk)
+      if (chunks != 1) return 1;
+      if (u4 == 6) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 6, false, true>), grid, block, 0, st, a, g_dbg);
+      else if (u4 == 8) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 8, false, true>), grid, block, 0, st, a, g_dbg);
+      else if (u4 == 4) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 4, false, true>), grid, block, 0, st, a, g_dbg);
+      else return 1;
+      return 0;
+    }
+  }
   if (g_dbg.buf && g_dbg.slot < g_dbg_launches) {
     if (u4 == 6) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 6, true>), grid, block, 0, st, a, g_dbg);
     else if (u4 == 8) hipLaunchKernelGGL((dec_gemm16_kernel<EPI, ACT, 8, true>), grid, block, 0, st, a, g_dbg);
@@ -717,6 +796,24 @@ int vy_dec_qkv(const void* x, const void* w, const void* bias, const float* cos_
   a.nq = h * 64; a.nkv = hk * 64; a.rope = cos_tab != nullptr;
   if (dec_gemm_go<DEC_QKV, VY_ACT_NONE>(a, d, 1, st)) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_dec_qkv: K = %d", d);
   VY_CHECK_LAUNCH("vy_dec_qkv");
+  return VY_OK;
+}
+
+// y[B][N] = bf16(act(LN(x) W^T + b) + residual), K one chunk.  residual / ln_g / ln_b may be NULL (no residual / x as is)
+int vy_dec_linear_ex(const void* x, int ldx, const void* w, const void* bias, const void* residual, int ldr, const void* ln_g,
+                     const void* ln_b, float ln_eps, void* y, int ldy, int B, int N, int K, int act, hipStream_t st) {
+  DecGemmArgs a{};
+  a.X = (const bf16*)x; a.W = (const bf16*)w; a.bias = (const bf16*)bias;
+  a.ldx = ldx; a.ldw = K; a.M = B; a.N = N; a.y = (bf16*)y; a.ldy = ldy;
+  a.residual = (const bf16*)residual; a.ldr = ldr;
+  a.ln_g = (const bf16*)ln_g; a.ln_b = (const bf16*)ln_b; a.ln_eps = ln_eps;
+  if (a.ln_g && (K % 8 || ((uintptr_t)ln_g & 15) || ((uintptr_t)ln_b & 15))) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_dec_linear_ex: LayerNorm operands");
+  int rc;
+  if (act == VY_ACT_GELU_ERF) rc = dec_gemm_go<DEC_STORE, VY_ACT_GELU_ERF>(a, K, 1, st);
+  else if (act == VY_ACT_GELU_TANH) rc = dec_gemm_go<DEC_STORE, VY_ACT_GELU_TANH>(a, K, 1, st);
+  else rc = dec_gemm_go<DEC_STORE, VY_ACT_NONE>(a, K, 1, st);
+  if (rc) VY_FAIL(VY_ERR_UNSUPPORTED, "vy_dec_linear_ex: K = %d", K);
+  VY_CHECK_LAUNCH("vy_dec_linear_ex");
   return VY_OK;
 }
 

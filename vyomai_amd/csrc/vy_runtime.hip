@@ -35,6 +35,8 @@ bool vy_dec_supported(int B, int d, int h, int hk, int dh, int ffn, int dtype);
 int vy_dec_qkv(const void* x, const void* w, const void* bias, const float* cos_tab, const float* sin_tab, int64_t pos0,
                const int* pos_dev, void* q, void* k, void* v, int64_t c_sb, int64_t c_sh, int64_t c_sl, int B, int d, int h,
                int hk, hipStream_t st);
+int vy_dec_linear_ex(const void* x, int ldx, const void* w, const void* bias, const void* residual, int ldr, const void* ln_g,
+                     const void* ln_b, float ln_eps, void* y, int ldy, int B, int N, int K, int act, hipStream_t st);
 int vy_dec_linear(const void* x, int ldx, const void* w, const void* bias, void* y, int ldy, int B, int N, int K, int act,
                   hipStream_t st);
 int vy_dec_linear_res_ln(const void* x, int ldx, const void* w, const void* bias, const void* residual, int ldr,
@@ -110,10 +112,21 @@ extern "C" int vy_decoder_step(const vy_decode_plan* p, const void* x, int64_t p
       rc = vy_attn_decode_ex(q, (int64_t)h * dh, dh, L.kcache, L.c_sb, L.c_sh, L.c_sl, L.vcache, L.c_sb, L.c_sh,
                              L.c_sl, ao, d, B, h, hk, pos + 1, pos_dev, dh, scale, p->dtype, stream);
       if (rc) return rc;
-      rc = vy_dec_linear_res_ln(ao, d, L.wo, L.bo, cur, d, L.ln1_w, L.ln1_b, p->eps_attn, a, d, part, B, d, d, VY_ACT_NONE, hst);
-      if (rc) return rc;
-      rc = vy_dec_linear(a, d, L.w1, L.b1, mid, p->ffn, B, p->ffn, d, p->act, hst);
-      if (rc) return rc;
+      // LN1's output feeds FFN1 only (the FFN residual is the layer input): the out-projection keeps whole rows per
+      // workgroup (K = d is one chunk: 16-column workgroups, bias + residual in the epilogue) and FFN1 normalises its
+      // input rows on the way in -- no split-K partials, no finish + LayerNorm launch: 6 links per layer instead of 7
+      static const int lnfold = [] { const char* e = getenv("VY_DEC_LNFOLD"); return e ? atoi(e) : 1; }();
+      if (lnfold) {
+        rc = vy_dec_linear_ex(ao, d, L.wo, L.bo, cur, d, nullptr, nullptr, 0.f, s, d, B, d, d, VY_ACT_NONE, hst);
+        if (rc) return rc;
+        rc = vy_dec_linear_ex(s, d, L.w1, L.b1, nullptr, 0, L.ln1_w, L.ln1_b, p->eps_attn, mid, p->ffn, B, p->ffn, d, p->act, hst);
+        if (rc) return rc;
+      } else {
+        rc = vy_dec_linear_res_ln(ao, d, L.wo, L.bo, cur, d, L.ln1_w, L.ln1_b, p->eps_attn, a, d, part, B, d, d, VY_ACT_NONE, hst);
+        if (rc) return rc;
+        rc = vy_dec_linear(a, d, L.w1, L.b1, mid, p->ffn, B, p->ffn, d, p->act, hst);
+        if (rc) return rc;
+      }
       void* nxt_l = hb[l & 1];   // FFN residual = the LAYER INPUT (reference models/decoder.py:241-250)
       rc = vy_dec_linear_res_ln(mid, p->ffn, L.w2, L.b2, cur, d, L.ln2_w, L.ln2_b, p->eps_ffn, nxt_l, d, part, B, d, p->ffn,
                                 VY_ACT_NONE, hst);
