@@ -324,3 +324,20 @@ def test_arena_copy_is_refreshed_in_place_after_load_state_dict():
     again = _shadow(w, torch.bfloat16)
     assert again.data_ptr() == view_before.data_ptr()
     assert torch.allclose(again.float(), w.detach().bfloat16().float())
+
+
+def test_zero_grad_after_an_unstepped_backward_starts_a_fresh_window():
+    """backward() without optimizer_step(), then train_step(): zero_grad() drops the finished-but-unstepped window (it
+    used to count as 'mid-accumulation' and return without clearing anything)."""
+    torch.manual_seed(0)
+    model = Tiny()
+    tr = _make_trainer(model)
+    x = torch.randn(4, 16)
+    tr.zero_grad()
+    tr.backward(model(x).pow(2).mean())
+    g1 = tr.arena.grad.clone()
+    assert g1.abs().sum() > 0
+    tr.zero_grad()
+    assert tr.arena.grad.abs().sum() == 0 and tr._micro == 0
+    tr.train_step(lambda: model(x).pow(2).mean())          # a complete step, no complaint about a second backward
+    assert tr.step_count == 1

@@ -2,7 +2,7 @@
     python tools/collect_profiles.py r02"""
 import glob, os, shutil, subprocess, sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{R}")
 dst = os.path.join(root, "profiles")
@@ -21,6 +21,9 @@ stats("roofline", "roofline_probe")
 stats("decode", "decode")
 stats("bench", "bench")
 stats("paligemma", "paligemma_decode")
+stats("prefill", "paligemma_prefill")
+stats("vlm", "vlm")
+stats("train", "train_step")
 dirs = [os.path.join(src, d) for d in ("pmc_fetch", "pmc_write", "pmc_hit")]
 if all(os.path.isdir(d) for d in dirs):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_pmc_json.py")] + dirs, capture_output=True, text=True)
@@ -34,9 +37,10 @@ if os.path.exists(tl):
     keep = [l for l in open(tl).read().splitlines() if l[:1] in " lf" and ("|" in l or "stamped" in l)]
     open(os.path.join(dst, f"{R}_decode_timeline.txt"), "w").write("\n".join(keep) + "\n")
     print("wrote", f"{R}_decode_timeline.txt")
-for log in ("roofline.log", "decode.log", "paligemma.log"):
+for log in ("roofline.log", "decode.log", "paligemma.log", "prefill.log", "vlm.log", "train.log"):
     p = os.path.join(src, log)
     if os.path.exists(p):
-        lines = [l for l in open(p).read().splitlines() if l.startswith(("{", "decode step", "PaliGemma shape"))]
+        lines = [l for l in open(p).read().splitlines()
+                 if l.startswith(("{", "decode step", "PaliGemma shape", "prefill + first token", "caption training", "train_only", "losses"))]
         if lines:
             open(os.path.join(dst, f"{R}_{log.replace('.log', '')}_run.txt"), "w").write("\n".join(lines) + "\n")

@@ -454,8 +454,9 @@ class FlatTrainer:
         return out
 
     def zero_grad(self) -> None:
-        if self._micro != 0:       # in the middle of an accumulation window: keep adding
+        if 0 < self._micro < self.accumulate_steps:   # in the middle of an accumulation window: keep adding
             return
+        self._micro = 0            # (a finished window that was never stepped is dropped here: its gradients are cleared)
         from .autograd_train import _wgrad_group
         _wgrad_group.discard()   # (only an aborted backward can have left deferred weight gradients behind)
         self.arena.zero_grad()
