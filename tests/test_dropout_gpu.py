@@ -294,10 +294,11 @@ def test_out_of_range_labels_are_ignored_and_flagged():
     m.lm_head.raise_on_label_error()                                # clean labels: no error
 
 
-@pytest.mark.parametrize("variant", [20, 21])
-def test_gemm_two_workgroups_per_cu_variants(variant):
-    """The experimental 4-wave 256 x 192 kernels (VY_GEMM_VARIANT 20 / 21) against fp64 and, bit for bit,
-    against the default selection."""
+@pytest.mark.parametrize("variant", [8, 9])
+def test_gemm_tile_variants_agree_with_the_default_selection(variant):
+    """The A/B knob that is left (VY_GEMM_VARIANT / vy_debug_set_gemm_variant: 8 / 9 force the 256 x 256 / 256 x 192 tiles of
+    the two-stage 32 x 32 x 16 kernel) against the default 16 x 16 x 32 kernels and fp64: same k order per output element,
+    so equal up to the rounding of the fp32 chain."""
     import ctypes as C
     from vyomai_amd import ops, _lib
     lib = _lib.load()
@@ -312,36 +313,9 @@ def test_gemm_two_workgroups_per_cu_variants(variant):
             y0 = ops.linear(x, w, b, act=act, residual=r)
             lib.vy_debug_set_gemm_variant(variant)
             y1 = ops.linear(x, w, b, act=act, residual=r)
-            assert torch.equal(y0, y1)
+            assert (y0.float() - y1.float()).abs().max() <= 2 ** -6 * max(1.0, float(y0.float().abs().max()))
             pre = x.double() @ w.double().t() + b.double()
             want = (O.gelu_erf(pre) if act else pre) + r.double()
             assert torch.allclose(y1.double(), want, atol=3e-2, rtol=1e-2)
-    finally:
-        lib.vy_debug_set_gemm_variant(-1)
-
-
-@pytest.mark.parametrize("act", [0, 1])
-def test_gemm_pipelined_epilogue_kernel(act):
-    """The persistent kernel that works the previous tile's epilogue off inside the next tile's k-loop (default for
-    whole-tile launches with >= 2 tiles per CU and a plain epilogue) against the one-shot kernels, bit for bit
-    (variant 31 = the default selection without it), and against fp64."""
-    import ctypes as C
-    from vyomai_amd import ops, _lib
-    lib = _lib.load()
-    lib.vy_debug_set_gemm_variant.argtypes = [C.c_int]
-    try:
-        for M, N, K in ((8192, 3072, 768), (16384, 2304, 832), (5120, 4992, 1024)):
-            x = rnd(M, K, seed=1).to(BF).to(DEV)
-            w = rnd(N, K, seed=2, scale=1 / math.sqrt(K)).to(BF).to(DEV)
-            b = rnd(N, seed=3, scale=0.1).to(BF).to(DEV)
-            lib.vy_debug_set_gemm_variant(31)
-            y0 = ops.linear(x, w, b, act=act)
-            lib.vy_debug_set_gemm_variant(-1)
-            y1 = ops.linear(x, w, b, act=act)
-            assert torch.equal(y0, y1), (M, N, K)
-            rows = slice(0, M, 37)
-            pre = x[rows].double() @ w.double().t() + b.double()
-            want = O.gelu_erf(pre) if act else pre
-            assert torch.allclose(y1[rows].double(), want, atol=3e-2, rtol=1e-2)
     finally:
         lib.vy_debug_set_gemm_variant(-1)

@@ -252,6 +252,10 @@ __device__ unsigned long long vy_gemm_clk[6];   // cycles, ticks, launches, prol
 // same-process A/B timing; not part of include/vyom_hip.h).  -1 = the default selection.
 int g_chains = 1;   // vy_set_concurrent_chains: launch chains the caller runs side by side
 int g_gemm_variant = -2;
+inline bool vy_m16_on() {   // VY_GEMM_M16=0: the two-stage 32 x 32 x 16 kernels instead of the 16 x 16 x 32 defaults
+  static const int v = [] { const char* e = getenv("VY_GEMM_M16"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
 inline int vy_gemm_variant() {
   if (g_gemm_variant == -2) { const char* e = getenv("VY_GEMM_VARIANT"); g_gemm_variant = e ? atoi(e) : -1; }
   return g_gemm_variant;
@@ -809,153 +813,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_kernel(
 // HBM/MALL rather than from L2 -- does: its loads for k-slice kt+2 stay in flight across the
 // barrier that ends slice kt, and the barrier wait is a COUNTED vmcnt (the GX youngest LDS-DMA
 // instructions of the wave, slice kt+2 of X, may still be outstanding).
-// ------------------------------------------------------------------------------------------
-template <int BN, int EPI, int ACT, bool GRAD>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_x3_kernel(
-    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
-    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq, int knob) {
-  constexpr int BM = 256, WGM = 4, WGN = 2, NW = 8;
-  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
-  VY_CLK_BEGIN(knob & 16)
-  constexpr int PX = BM / 8, PW = BN / 8;   // 1-KiB LDS-DMA pieces (8 rows x 128 B) per k-slice
-  constexpr int GX = PX / NW, GW = PW / NW;
-  static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
-  constexpr int XT = BM * ROWB, WT = BN * ROWB;        // bytes of one X / W k-slice
-  constexpr int WOFF = 3 * XT;
-  constexpr int EROW = BN * 2 + 16;
-  constexpr int LDS_BYTES = vy_cmax(3 * XT + 2 * WT, epi_lds_bytes(BM, BN, EPI, 1));
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  int tile_m, tile_n;
-  tile_of(blockIdx.x, gridDim.x, tiles_n, !(knob & 32), tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int lrow = lane >> 3, slot = lane & 7;
-  const bf16* xsrc[GX]; int xk[GX];
-  const bf16* wsrc[GW]; int wk[GW];
-#pragma unroll
-  for (int t = 0; t < GX; ++t) {
-    const int R = (wave + NW * t) * 8 + lrow;
-    const int g = slot ^ ((R >> 1) & 7);
-    int gm = m0 + R; gm = gm < M ? gm : M - 1;
-    xsrc[t] = X + (int64_t)gm * ldx + g * 8;
-    xk[t] = g * 8;
-  }
-#pragma unroll
-  for (int t = 0; t < GW; ++t) {
-    const int R = (wave + NW * t) * 8 + lrow;
-    const int g = slot ^ ((R >> 1) & 7);
-    int gn = n0 + R; gn = gn < N ? gn : N - 1;
-    wsrc[t] = W + (int64_t)gn * ldw + g * 8;
-    wk[t] = g * 8;
-  }
-  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
-  const bool ktail = (K % BK) != 0;
-  const int KT = (K + BK - 1) / BK;
-
-  auto stage_x = [&](int kt) {
-    char* xb = smem + (kt % 3) * XT;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int t = 0; t < GX; ++t) {
-      const bf16* s = xsrc[t] + k0;
-      if (ktail && k0 + xk[t] >= K) s = zero;
-      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, 0, 0);
-    }
-  };
-  auto stage_w = [&](int kt) {
-    char* wb = smem + WOFF + (kt & 1) * WT;
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int t = 0; t < GW; ++t) {
-      const bf16* s = wsrc[t] + k0;
-      if (ktail && k0 + wk[t] >= K) s = zero;
-      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s, (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
-  const int xrow_off = (wm * 32 * TM + fr) * ROWB;
-  const int wrow_off = (wn * 32 * TN + fr) * ROWB;
-
-  // hidden fragment reads with counted lgkmcnt (as in gemm_nt_bf16_kernel)
-  unsigned xa[4], wa[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
-    xa[ks] = vy_lds_addr(smem) + xrow_off + coff;
-    wa[ks] = vy_lds_addr(smem) + WOFF + wrow_off + coff;
-  }
-  bf16x8 wf[2][TN], xf[2][TM];
-  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
-    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; w_[i] = vy_lds_read128_off<i * 32 * ROWB>(wbase); });
-    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; x_[j] = vy_lds_read128_off<j * 32 * ROWB>(xbase); });
-  };
-  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
-#pragma unroll
-    for (int i = 0; i < TN; ++i) vy_tie(w_[i]);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) vy_tie(x_[j]);
-  };
-
-  // the wave's LDS-DMA queue, oldest first, at the wait that ends slice kt: X(kt+1), W(kt+1), X(kt+2)
-  stage_x(0);
-  stage_w(0);
-  if (KT > 1) stage_x(1);
-  if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  VY_CLK_MARK(0)
-  read_frags(wa[0], xa[0], wf[0], xf[0]);
-  int xbuf = 0;   // kt % 3
-  for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT) stage_w(kt + 1);
-    if (kt + 2 < KT) stage_x(kt + 2);
-    const unsigned xo = xbuf * XT, wo = (kt & 1) * WT;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) {
-        read_frags(wa[ks + 1] + wo, xa[ks + 1] + xo, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      tie_frags(wf[ks & 1], xf[ks & 1]);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    xbuf = xbuf == 2 ? 0 : xbuf + 1;
-    if (kt + 1 < KT) read_frags(wa[0] + (WT - wo), xa[0] + xbuf * XT, wf[0], xf[0]);
-  }
-  VY_CLK_MARK(1)
-  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
-  VY_CLK_MARK(2)
-  VY_CLK_END()
-}
-
-// ------------------------------------------------------------------------------------------
-// The same kernel on mfma_f32_16x16x32_bf16: 4 x 6 blocks of 16 x 16 per wave (96 accumulator registers as before),
+//
+// On mfma_f32_16x16x32_bf16 (the 32 x 32 x 16 form of this kernel was removed in round 3 -- identical outputs, slower):
+// 4 x 6 blocks of 16 x 16 per wave (96 accumulator registers),
 // 24 MFMAs per 32-deep k-step, two k-steps per stage.  Same LDS image, same swizzle (conflict-free for this
 // fragment shape too: rows lane & 15, chunk 4 ks + (lane >> 4)), same ring, same epilogue (a lane still owns quads of 4
 // consecutive columns of one row).  Why: the chip holds a higher clock on this MFMA shape and the loop needs fewer
@@ -1459,619 +1319,6 @@ void launch_mid(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
     hipLaunchKernelGGL((gemm_nt_bf16_m16_kernel<BM, BN, WGM, WGN, EPI, ACT, GRAD>), dim3(tiles), dim3(NT), 0,
                        st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// PERSISTENT 256 x 192 kernel with the epilogue of tile t software-pipelined into the k-loop of tile t+1.
-//
-// Measured on the forward launches of a layer (tools/gemm_diag2.py, workgroup 0, K = 768): the k-loop is 34 k
-// cycles, the epilogue 12 k (plain), 21 k (+GELU or +residual), 24 k (+RoPE): a third of every launch is spent
-// with the matrix pipe idle while ALL 256 workgroups convert, stage and store at once.  Here a workgroup keeps
-// its CU for several tiles; when a tile's last k-slice is done its accumulators (+ bias) are packed to bf16 in
-// REGISTERS (96 fp32 -> 48 packed registers, still two waves per SIMD) and the workgroup goes straight on to
-// the next tile; during that tile's first 12 k-stages every wave works off one parked pair of quads per stage:
-// activation, v_permlane32_swap so that a lane holds 8 consecutive columns, one 16-byte store.
-//   * the two waves of a SIMD run the same program in lockstep (one barrier per stage): waves 0-3 drain
-//     behind k-step 0, waves 4-7 behind k-step 2 (MI355X_MICROARCH.md, two waves per SIMD, item 9);
-//   * the parked value is made opaque (empty asm) at the drain point, or the compiler applies the activation
-//     when it parks -- the serial epilogue again;
-//   * (a variant that transposed the parked tile through a per-wave LDS scratch to store whole 128-byte lines
-//     measured slower than no pipelining at all: 2-stage ring + scratch traffic.)
-// The parked tile's global stores are issued AFTER the stage's LDS-DMA (younger in the wave's memory queue)
-// and counted in the stage's vmcnt, so the wait for the next slice never waits for a store.  Only the LAST
-// tile of a workgroup runs the staged LDS epilogue.  A launch with one tile per CU gains nothing (the launcher
-// keeps the one-shot kernel for those).  Arithmetic is that of gemm_epilogue (bias -> bf16 -> activation on
-// the bf16 value -> bf16): bit-identical.
-// ------------------------------------------------------------------------------------------
-template <int ACT>
-__global__ __launch_bounds__(512, 1) void gemm_nt_bf16_pipe_kernel(
-    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
-    int K, int tiles_n, int tiles_total, EpiPlain<bf16> ep, int knob) {
-  constexpr int BM = 256, BN = 192, WGM = 4, WGN = 2, NW = 8;
-  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);   // 2, 3
-  constexpr int PX = BM / 8, PW = BN / 8;
-  constexpr int GX = PX / NW, GW = PW / NW;                  // 4, 3
-  constexpr int XT = BM * ROWB, WT = BN * ROWB;
-  constexpr int WOFF = 3 * XT;
-  constexpr int EROW = BN * 2 + 16;
-  constexpr int LDS_BYTES = 3 * XT + 2 * WT > BM * EROW ? 3 * XT + 2 * WT : BM * EROW;
-  constexpr int NP = TN * TM * 2;            // 12 pairs of quads (8 columns) per lane and tile
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 1) & 7;
-  const int lrow = lane >> 3, slot = lane & 7;
-  const int KT = K / BK;   // the launcher guarantees K % 64 == 0, KT >= 12, whole tiles
-
-  unsigned xa[4], wa[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
-    xa[ks] = vy_lds_addr(smem) + (wm * 32 * TM + fr) * ROWB + coff;
-    wa[ks] = vy_lds_addr(smem) + WOFF + (wn * 32 * TN + fr) * ROWB + coff;
-  }
-  bf16x8 wf[2][TN], xf[2][TM];
-  auto read_frags = [&](unsigned wbase, unsigned xbase, bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
-    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; w_[i] = vy_lds_read128_off<i * 32 * ROWB>(wbase); });
-    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; x_[j] = vy_lds_read128_off<j * 32 * ROWB>(xbase); });
-  };
-  auto tie_frags = [&](bf16x8 (&w_)[TN], bf16x8 (&x_)[TM]) {
-#pragma unroll
-    for (int i = 0; i < TN; ++i) vy_tie(w_[i]);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) vy_tie(x_[j]);
-  };
-
-  f32x16 acc[TN][TM];
-  // the previous tile, bf16(acc + bias): pair p = (i * TM + j) * 2 + h holds the quads rg = 2h and 2h + 1
-  u32x2 parked[NP][2];
-  bool have_parked = false;   // workgroup-uniform
-  int pm0 = 0, pn0 = 0;
-
-  // one parked pair (two quads, 8 output columns), worked off over the four k-steps of one stage: k-step s
-  // applies the activation to element s of both quads -- a few VALU instructions that the scheduler is told
-  // to interleave with that k-step's six MFMAs (sched_group_barrier), because a wave issues in order: a
-  // VALU block between two MFMA clusters delays the second cluster by its whole length -- and k-step 3 ends
-  // with the lane-half swap (T21: v_permlane32_swap, a lane then holds 8 consecutive columns) and one
-  // 16-byte store.
-  bf16x4 da, db;   // the pair in flight
-  auto drain_begin = [&](auto p_c) {
-    constexpr int P = decltype(p_c)::value;
-    u32x2 a = parked[P][0], b = parked[P][1];
-    // the compiler must not do this work at park time (it would be the old serial epilogue again)
-    asm volatile("" : "+v"(a), "+v"(b));
-    da = __builtin_bit_cast(bf16x4, a);
-    db = __builtin_bit_cast(bf16x4, b);
-  };
-  auto drain_step = [&](int e) {
-    if constexpr (ACT != VY_ACT_NONE) {
-      da[e] = (bf16)vy_act_fwd_fast<ACT>((float)da[e]);
-      db[e] = (bf16)vy_act_fwd_fast<ACT>((float)db[e]);
-    }
-  };
-  auto drain_end = [&](auto p_c) {
-    constexpr int P = decltype(p_c)::value;
-    constexpr int i = P / (TM * 2), j = (P / 2) % TM, hq = P % 2;
-    const u32x2 a = __builtin_bit_cast(u32x2, da), b = __builtin_bit_cast(u32x2, db);
-    // vdst = quad rg (a), src = quad rg + 1 (b): lanes 32-63 of a swap with lanes 0-31 of b
-    auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
-    auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
-    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
-    const int64_t m = pm0 + wm * 32 * TM + j * 32 + fr;
-    const int n = pn0 + wn * 32 * TN + i * 32 + 16 * hq + 8 * fh;
-    if (n + 8 <= N) {
-      *reinterpret_cast<u32x4*>(ep.y + m * ep.ldy + n) = o;   // (write-through here measured 15-25 % slower)
-    } else if (n < N) {   // the ragged end of the last column tile
-      const bf16x8 o8 = __builtin_bit_cast(bf16x8, o);
-      for (int e = 0; e < 8 && n + e < N; ++e) ep.y[m * ep.ldy + n + e] = o8[e];
-    }
-  };
-
-  for (int b = blockIdx.x; b < tiles_total; b += gridDim.x) {
-    int tile_m, tile_n;
-    tile_of(b, tiles_total, tiles_n, !(knob & 32), tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const bf16* xsrc[GX];
-    const bf16* wsrc[GW];
-#pragma unroll
-    for (int t = 0; t < GX; ++t) {
-      const int R = (wave + NW * t) * 8 + lrow;
-      xsrc[t] = X + (int64_t)(m0 + R) * ldx + (slot ^ ((R >> 1) & 7)) * 8;
-    }
-    // the last column tile may reach beyond N (ragged widths, e.g. a vocabulary): rows of W that do not exist are read
-    // from 16 zero bytes, so the columns beyond N come out as the bias guard's 0 and are never stored
-    const bool ntail = n0 + BN > N;   // workgroup-uniform
-    int64_t wstep[GW];
-#pragma unroll
-    for (int t = 0; t < GW; ++t) {
-      const int R = (wave + NW * t) * 8 + lrow;
-      const bool ok = n0 + R < N;
-      wsrc[t] = ok ? W + (int64_t)(n0 + R) * ldw + (slot ^ ((R >> 1) & 7)) * 8 : reinterpret_cast<const bf16*>(vy_zero16);
-      wstep[t] = ok ? BK : 0;
-    }
-    auto stage_x = [&](int kt) {
-      char* xb = smem + (kt % 3) * XT;
-#pragma unroll
-      for (int t = 0; t < GX; ++t)
-        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(xsrc[t] + kt * BK), (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, 0, 0);
-    };
-    auto stage_w = [&](int kt) {
-      char* wb = smem + WOFF + (kt & 1) * WT;
-#pragma unroll
-      for (int t = 0; t < GW; ++t)
-        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)(wsrc[t] + (ntail ? kt * wstep[t] : (int64_t)kt * BK)),
-                                         (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
-    };
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // (every wave passed the barrier that ended the previous tile's last stage: its LDS reads are retired)
-    stage_x(0);
-    stage_w(0);
-    stage_x(1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(wa[0], xa[0], wf[0], xf[0]);
-    int xbuf = 0;   // kt % 3
-    int kt = 0;
-    // one k-stage; DR: one parked pair (16 output bytes per lane) rides between its k-steps
-    auto stage_body = [&](auto dr_c, auto p_c) {
-      constexpr bool DR = decltype(dr_c)::value;
-      if (kt + 1 < KT) stage_w(kt + 1);
-      if (kt + 2 < KT) stage_x(kt + 2);
-      const unsigned xo = xbuf * XT, wo = (kt & 1) * WT;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) {
-          read_frags(wa[ks + 1] + wo, xa[ks + 1] + xo, wf[(ks + 1) & 1], xf[(ks + 1) & 1]);
-          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        tie_frags(wf[ks & 1], xf[ks & 1]);
-        if constexpr (DR && ACT != VY_ACT_NONE) {
-          // activation of element ks of the pair in flight, interleaved with this k-step's MFMAs
-          if (ks == 0) drain_begin(p_c);
-          drain_step(ks);
-#pragma unroll
-          for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-          for (int g = 0; g < TN * TM; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // then up to 7 VALU
-            __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);   // and a transcendental
-          }
-          if (ks == 3) drain_end(p_c);
-        } else {
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][i], xf[ks & 1][j], acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_s_setprio(0);
-          if constexpr (DR) {
-            if (ks == 0) { drain_begin(p_c); drain_end(p_c); }
-          }
-        }
-      }
-      // oldest first: X(kt+1), W(kt+1), X(kt+2), this stage's parked store
-      if constexpr (DR) {
-        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      xbuf = xbuf == 2 ? 0 : xbuf + 1;
-      if (kt + 1 < KT) read_frags(wa[0] + (WT - wo), xa[0] + xbuf * XT, wf[0], xf[0]);
-      ++kt;
-    };
-    if (have_parked) {
-      vy_static_for<NP>([&](auto p_c) { stage_body(std::true_type{}, p_c); });
-      have_parked = false;
-    }
-    while (kt < KT) stage_body(std::false_type{}, std::integral_constant<int, 0>{});
-
-    if (b + (int)gridDim.x < tiles_total) {
-      // more tiles for this workgroup: park bf16(acc + bias) in registers and go on
-      const bf16* biasp = ep.bias;
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          float bq[4] = {0.f, 0.f, 0.f, 0.f};
-          if (biasp) {
-            const int nb_ = n0 + wn * 32 * TN + i * 32 + 8 * rg + 4 * fh;
-            if (nb_ + 3 < N && ((reinterpret_cast<uintptr_t>(biasp + nb_) & 7) == 0)) {
-              const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(biasp + nb_);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) bq[e] = (float)b4[e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) bq[e] = nb_ + e < N ? (float)biasp[nb_ + e] : 0.f;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            bf16x4 w4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w4[e] = (bf16)(acc[i][j][4 * rg + e] + bq[e]);
-            parked[(i * TM + j) * 2 + (rg >> 1)][rg & 1] = __builtin_bit_cast(u32x2, w4);
-          }
-        }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the bias loads; the last parked store)
-      have_parked = true;
-      pm0 = m0; pn0 = n0;
-    } else {
-      // last tile of this workgroup: the staged epilogue (the ring is free: every wave is past the last barrier)
-      EpiQkv<bf16> eq{};
-      gemm_epilogue<BM, BN, WGM, WGN, 0, ACT, false, 1, false>(acc, smem, m0, n0, M, N, ep, eq);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// 256 x 192 tile on FOUR waves (2 x 2, 128 x 96 per wave, 192 accumulator registers), k-slices of 32
-// with X in a three-deep and W in a two-deep LDS ring: 72 KiB, so TWO workgroups are resident per CU.
-// Why: with one 8-wave workgroup per CU every wave of the CU is in the same phase -- all issue their
-// LDS-DMA, all run MFMAs, all sit in the epilogue (bias / activation / staging / 128-byte stores,
-// 6-11 us at K = 768) while the matrix pipe idles.  Two independent workgroups drift apart: one's
-// epilogue, barrier waits and LDS-DMA issue run under the other's MFMAs (each SIMD hosts one wave of
-// each).  A wave's 128 x 96 sub-tile also needs fewer LDS bytes per FLOP (7 ds_read_b128 per 12 MFMAs
-// against 5 per 6).  Needs >= 2 tiles per CU to pay: used for N >= 2304 at large M.
-// ------------------------------------------------------------------------------------------
-template <int EPI, int ACT, bool GRAD, int VAR>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_pp_kernel(
-    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
-    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
-  constexpr int BM = 256, BN = 192, WGM = 2, WGN = 2, NW = 4;
-  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);   // 4, 3
-  constexpr int RK = 32, RROW = 64;
-  constexpr int PX = BM / 16, PW = BN / 16;          // 1-KiB pieces (16 rows x 64 B) per slice
-  constexpr int GX = PX / NW, GW = PW / NW;          // 4 and 3 per wave
-  static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
-  constexpr int XT = BM * RROW, WT = BN * RROW;      // 16 KiB, 12 KiB
-  constexpr int WOFF = 3 * XT;
-  constexpr int EROW = BN * 2 + 16;
-  constexpr int PASSES = 2;
-  constexpr int LDS_BYTES = 3 * XT + 2 * WT;
-  static_assert(epi_lds_bytes(BM, BN, EPI, PASSES) <= LDS_BYTES, "epilogue band (+ rotary table) must fit in the ring");
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  // LDS-DMA through buffer descriptors: ONE per-lane byte offset per operand (row of the first piece,
-  // pre-swizzled 16-byte chunk); tile origin, piece and k-slice go into the scalar offset -- the 14
-  // pointer registers of the global_load form do not fit beside 192 accumulators.  The launcher only
-  // takes this kernel for whole tiles (M % 256 == 0, N % 192 == 0, K % 32 == 0, operands < 4 GiB).
-  const int lrow = lane >> 2, slot = lane & 3;
-  const int g = slot ^ ((lrow >> 2) & 3);   // (R >> 2) & 3 with R = 16 * piece + lrow
-  const unsigned xvoff = (unsigned)(((wave * 16 + lrow) * ldx + g * 8) * 2);
-  const unsigned wvoff = (unsigned)(((wave * 16 + lrow) * ldw + g * 8) * 2);
-  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)X, 0, (int)(unsigned)(((int64_t)(M - 1) * ldx + K) * 2), 0x00020000);
-  const auto wrs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, (int)(unsigned)(((int64_t)(N - 1) * ldw + K) * 2), 0x00020000);
-  const unsigned xs0 = (unsigned)((int64_t)m0 * ldx * 2), ws0 = (unsigned)((int64_t)n0 * ldw * 2);
-  const unsigned xps = (unsigned)(NW * 16 * ldx * 2), wps = (unsigned)(NW * 16 * ldw * 2);   // piece stride
-  const int KT = K / RK;
-
-  auto stage_x = [&](int kt, int xb_idx) {
-    char* xb = smem + xb_idx * XT;
-    const unsigned so = xs0 + (unsigned)(kt * RK * 2);
-#pragma unroll
-    for (int t = 0; t < GX; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (VY_LDS void*)(xb + (wave + NW * t) * 1024), 16, xvoff, so + t * xps, 0, 0);
-  };
-  auto stage_w = [&](int kt) {
-    char* wb = smem + WOFF + (kt & 1) * WT;
-    const unsigned so = ws0 + (unsigned)(kt * RK * 2);
-#pragma unroll
-    for (int t = 0; t < GW; ++t)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, wvoff, so + t * wps, 0, 0);
-  };
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
-  unsigned xa[2], wa[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
-    xa[ks] = vy_lds_addr(smem) + (wm * 32 * TM + fr) * RROW + coff;
-    wa[ks] = vy_lds_addr(smem) + WOFF + (wn * 32 * TN + fr) * RROW + coff;
-  }
-  bf16x8 wf[TN], xf[TM];
-  auto read_w = [&](unsigned wbase) {
-    vy_static_for<TN>([&](auto i_c) { constexpr int i = decltype(i_c)::value; wf[i] = vy_lds_read128_off<i * 32 * RROW>(wbase); });
-  };
-  auto read_x = [&](unsigned xbase) {
-    vy_static_for<TM>([&](auto j_c) { constexpr int j = decltype(j_c)::value; xf[j] = vy_lds_read128_off<j * 32 * RROW>(xbase); });
-  };
-  auto tie_all = [&]() {
-#pragma unroll
-    for (int i = 0; i < TN; ++i) vy_tie(wf[i]);
-#pragma unroll
-    for (int j = 0; j < TM; ++j) vy_tie(xf[j]);
-  };
-
-  // the wave's LDS-DMA queue, oldest first, at the wait that ends slice kt: X(kt+1), W(kt+1), X(kt+2)
-  stage_x(0, 0);
-  stage_w(0);
-  if (KT > 1) stage_x(1, 1);
-  if (KT > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  int xbuf = 0;   // kt % 3
-  for (int kt = 0; kt < KT; ++kt) {
-    const unsigned xo = xbuf * XT, wo = (kt & 1) * WT;
-    const int xnext2 = xbuf == 0 ? 2 : xbuf - 1;   // (kt + 2) % 3
-    if constexpr (VAR == 0) {
-      if (kt + 1 < KT) stage_w(kt + 1);
-      if (kt + 2 < KT) stage_x(kt + 2, xnext2);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        read_w(wa[ks] + wo);
-        read_x(xa[ks] + xo);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        tie_all();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-          for (int i = 0; i < TN; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      }
-    } else {
-      // fragments of k-step 0 first, the LDS-DMA issue of the slices ahead in the shadow of its MFMAs;
-      // k-step 1's fragments are requested as soon as the registers they land in are free
-      read_w(wa[0] + wo);
-      read_x(xa[0] + xo);
-      if (kt + 1 < KT) stage_w(kt + 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tie_all();
-      __builtin_amdgcn_s_setprio(1);
-      vy_static_for<TM>([&](auto j_c) {
-        constexpr int j = decltype(j_c)::value;
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-        xf[j] = vy_lds_read128_off<j * 32 * RROW>(xa[1] + xo);
-      });
-      __builtin_amdgcn_s_setprio(0);
-      read_w(wa[1] + wo);
-      if (kt + 2 < KT) stage_x(kt + 2, xnext2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tie_all();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GX) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    xbuf = xbuf == 2 ? 0 : xbuf + 1;
-  }
-  // every wave has passed the last barrier after retiring its LDS reads: the ring is free
-  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD, PASSES>(acc, smem, m0, n0, M, N, ep, eq);
-}
-
-// ------------------------------------------------------------------------------------------
-// deep-pipelined variant for the large-M (training) shapes: 256 x BN tile, 8 waves (4 x 2),
-// k-slices of 32 staged by LDS-DMA into a 4-deep LDS ring.  Three slices are always in flight:
-// a slice is waited for with a COUNTED vmcnt three iterations after it was issued, one raw
-// s_barrier per slice (no vmcnt(0) drain anywhere in the loop), so the L2 -> LDS latency is
-// covered by three slices of MFMA work instead of stalling every iteration.
-// LDS image of a slice: [rows][32] bf16 (64-byte rows), 16-byte chunk index XOR (row>>2)&3 on the
-// LDS-DMA source address and on the ds_read_b128: conflict-free for the 16-lane read groups.
-// ------------------------------------------------------------------------------------------
-#define VY_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
-template <int BN, int EPI, int ACT, bool GRAD, int VAR, int NS>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_ring_kernel(
-    const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw, int M, int N,
-    int K, int tiles_n, EpiPlain<bf16> ep, EpiQkv<bf16> eq) {
-  constexpr int BM = 256, WGM = 4, WGN = 2, NW = 8;
-  constexpr int TM = 2, TN = BN / 64;
-  constexpr int RK = 32, RROW = 64;  // NS slices in the LDS ring, NS - 1 in flight
-  constexpr int PX = BM / 16, PW = BN / 16;          // 1-KiB pieces (16 rows x 64 B) per slice
-  constexpr int GX = PX / NW, GW = (PW + NW - 1) / NW;  // per wave: 2 and 2 (the last may be absent)
-  constexpr int STAGE = (BM + BN) * RROW;
-  constexpr int EROW = BN * 2 + 16;
-  constexpr int LDS_BYTES = vy_cmax(NS * STAGE, epi_lds_bytes(BM, BN, EPI, 1));
-  static_assert(PX % NW == 0, "X pieces must divide over the waves");
-  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = wg / tiles_n, tile_n = wg - tile_m * tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int lrow = lane >> 2, slot = lane & 3;
-  const bf16* xsrc[GX]; int xk[GX];
-  const bf16* wsrc[GW]; int wk[GW];
-#pragma unroll
-  for (int t = 0; t < GX; ++t) {
-    const int R = (wave + NW * t) * 16 + lrow;
-    const int g = slot ^ ((R >> 2) & 3);
-    int gm = m0 + R; gm = gm < M ? gm : M - 1;
-    xsrc[t] = X + (int64_t)gm * ldx + g * 8;
-    xk[t] = g * 8;
-  }
-#pragma unroll
-  for (int t = 0; t < GW; ++t) {
-    const int R = (wave + NW * t) * 16 + lrow;
-    const int g = slot ^ ((R >> 2) & 3);
-    int gn = n0 + R; gn = gn < N ? gn : N - 1;
-    wsrc[t] = W + (int64_t)gn * ldw + g * 8;
-    wk[t] = g * 8;
-  }
-  // LDS-DMA instructions this wave issues per slice (wave-uniform): all X pieces + its W pieces
-  const bool w_last = (PW % NW == 0) || (wave + NW * (GW - 1) < PW);
-  const bf16* zero = reinterpret_cast<const bf16*>(vy_zero16);
-  const bool ktail = (K % RK) != 0;
-  const int KT = (K + RK - 1) / RK;
-
-  // one LDS-DMA piece of slice kt: pieces 0..GX-1 are X, GX..GX+GW-1 are W
-  auto stage_piece = [&](int kt, int pc) {
-    char* xb = smem + (kt % NS) * STAGE;
-    char* wb = xb + BM * RROW;
-    const int k0 = kt * RK;
-    if (pc < GX) {
-      const bf16* s = xsrc[pc] + k0;
-      if (ktail && k0 + xk[pc] >= K) s = zero;
-      __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
-                                       (VY_LDS void*)(xb + (wave + NW * pc) * 1024), 16, 0, 0);
-    } else {
-      const int t = pc - GX;
-      if (t < GW - 1 || w_last) {
-        const bf16* s = wsrc[t] + k0;
-        if (ktail && k0 + wk[t] >= K) s = zero;
-        __builtin_amdgcn_global_load_lds((const VY_GLOBAL void*)s,
-                                         (VY_LDS void*)(wb + (wave + NW * t) * 1024), 16, 0, 0);
-      }
-    }
-  };
-  auto stage = [&](int kt) {
-#pragma unroll
-    for (int pc = 0; pc < GX + GW; ++pc) stage_piece(kt, pc);
-  };
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = lane & 31, fh = lane >> 5, fsw = (fr >> 2) & 3;
-  const int xrow_off = (wm * 32 * TM + fr) * RROW;
-  const int wrow_off = (wn * 32 * TN + fr) * RROW;
-
-  auto wait_landed = [&](int younger) {  // all but the loads of `younger` later slices are done
-    if (w_last) {  // GX + GW = 4 loads per slice
-      if (younger >= 3) VY_WAIT_VM(12); else if (younger == 2) VY_WAIT_VM(8); else if (younger == 1) VY_WAIT_VM(4); else VY_WAIT_VM(0);
-    } else {       // one W piece less
-      if (younger >= 3) VY_WAIT_VM(9); else if (younger == 2) VY_WAIT_VM(6); else if (younger == 1) VY_WAIT_VM(3); else VY_WAIT_VM(0);
-    }
-  };
-  auto read_frags = [&](int kt, int ks, bf16x8 (&wf)[TN], bf16x8 (&xf)[TM]) {
-    const char* xb = smem + (kt % NS) * STAGE;
-    const char* wb = xb + BM * RROW;
-    const int coff = (((ks * 2 + fh) ^ fsw) << 4);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-      wf[i] = *reinterpret_cast<const bf16x8*>(wb + wrow_off + i * 32 * RROW + coff);
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-      xf[j] = *reinterpret_cast<const bf16x8*>(xb + xrow_off + j * 32 * RROW + coff);
-  };
-  auto mma = [&](bf16x8 (&wf)[TN], bf16x8 (&xf)[TM]) {
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
-  };
-
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < KT) stage(s);
-
-  if constexpr (VAR == 0) {
-    for (int kt = 0; kt < KT; ++kt) {
-      wait_landed(min(NS - 2, KT - 1 - kt));
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + NS - 1 < KT) stage(kt + NS - 1);  // refills the buffer every wave finished reading
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 wf[TN], xf[TM];
-        read_frags(kt, ks, wf, xf);
-        mma(wf, xf);
-      }
-    }
-  } else if constexpr (VAR == 1) {
-    // MFMAs first: the matrix pipe starts right after the barrier, the LDS-DMA issue of the
-    // slice three ahead rides in the shadow of the first k-step's MFMAs
-    for (int kt = 0; kt < KT; ++kt) {
-      wait_landed(min(NS - 2, KT - 1 - kt));
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      bf16x8 wf[TN], xf[TM], wf1[TN], xf1[TM];
-      read_frags(kt, 0, wf, xf);
-      read_frags(kt, 1, wf1, xf1);
-      __builtin_amdgcn_s_setprio(1);
-      mma(wf, xf);
-      __builtin_amdgcn_s_setprio(0);
-      if (kt + NS - 1 < KT) stage(kt + NS - 1);
-      __builtin_amdgcn_s_setprio(1);
-      mma(wf1, xf1);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  } else {
-    // VAR 2: software-pipelined fragments: the first k-step's fragments of slice kt+1 are read at
-    // the end of iteration kt (slice kt+1 is known landed one iteration early), so every barrier
-    // is followed immediately by MFMAs; LDS-DMA pieces are spread between the MFMA groups.
-    bf16x8 wf[TN], xf[TM], wf1[TN], xf1[TM];
-    // simple, safe prologue: everything issued so far except the youngest slice has landed
-    if (KT >= 3) { wait_landed(1); } else { wait_landed(0); }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(0, 0, wf, xf);
-    for (int kt = 0; kt < KT; ++kt) {
-      read_frags(kt, 1, wf1, xf1);
-      if (kt + NS - 1 < KT) { stage_piece(kt + NS - 1, 0); stage_piece(kt + NS - 1, 1); }
-      __builtin_amdgcn_s_setprio(1);
-      mma(wf, xf);
-      __builtin_amdgcn_s_setprio(0);
-      if (kt + NS - 1 < KT) { stage_piece(kt + NS - 1, 2); stage_piece(kt + NS - 1, 3); }
-      if (kt + 1 < KT) read_frags(kt + 1, 0, wf, xf);  // slice kt+1 landed before this iteration
-      __builtin_amdgcn_s_setprio(1);
-      mma(wf1, xf1);
-      __builtin_amdgcn_s_setprio(0);
-      // before the next iteration: slice kt+2 must have landed (only slice kt+3 may be in flight)
-      if (kt + 1 < KT) {
-        wait_landed(kt + 3 < KT ? 1 : 0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-    }
-  }
-  __syncthreads();  // every wave is done with the ring before the epilogue reuses the LDS
-  gemm_epilogue<BM, BN, WGM, WGN, EPI, ACT, GRAD>(acc, smem, m0, n0, M, N, ep, eq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2825,102 +2072,29 @@ int launch_bf16(const bf16* X, int64_t ldx, const bf16* W, int64_t ldw, int64_t 
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
   } else {
     const int tn = (int)vy_cdiv(N, 192), tm = (int)vy_cdiv(M, 256);
-    // default: 2-stage 64-deep tiles.  256 x 192 divides N in {768, 2304} x M = 16384 into whole
-    // multiples of the 256 CUs; 256 x 256 (fewer L2 bytes per FLOP) where N is wide enough for
-    // whole rounds anyway (FFN1, vocabulary).  VY_GEMM_VARIANT selects the experimental ring
-    // kernels (0-2) or forces a tile (8/9) for A/B runs in one process.
-    // Default (var < 0): N >= 3072 -> two-stage 256 x 256; otherwise 256 x 192 with the X operand in a
-    // three-deep ring (gemm_nt_bf16_x3_kernel): equal or slightly slower on warm micro-benchmarks, +1 %
-    // inside the training step where the activations come from HBM/MALL.  16 = the two-stage 256 x 192.
-    const int var0 = vy_gemm_variant();
-    int var = var0 < 0 ? 14 : (var0 == 16 ? -1 : var0);
+    // Large M.  256 x 192 tiles divide N in {768, 2304} x M = 16384 into whole multiples of the 256 CUs (X operand in a
+    // three-deep ring: gemm_nt_bf16_x3m16_kernel); 256 x 256 (fewer L2 bytes per FLOP) where N is wide enough for whole
+    // rounds anyway (FFN1, the dgrad of FFN2, the vocabulary projection).  Both on mfma_f32_16x16x32_bf16.
+    // VY_GEMM_VARIANT (A/B runs in one process, tools/exp_gemm.py): 8 / 9 force the 256 x 256 / 256 x 192 tiles of the
+    // two-stage 32 x 32 x 16 kernel, 40 / 41 force the two default kernels whatever N.  The experimental kernels of rounds
+    // 1-2 (persistent pipelined epilogue, two 4-wave workgroups per CU, 4- and 5-slot rings of 32-wide slices, the
+    // 32 x 32 x 16 X-ring) measured level or behind these on every box and were removed in round 3.
+    const int var = vy_gemm_variant();
     const bool wide = (N >= 3072);
-    const bool pp_ok = M % 256 == 0 && N % 192 == 0 && K % 32 == 0 && M * ldx * 2 < (int64_t)0xffffffffll &&
-                       N * ldw * 2 < (int64_t)0xffffffffll;
-    static const int pp_min_n = [] { const char* e = getenv("VY_GEMM_PP_MIN_N"); return e ? atoi(e) : 0; }();
-    if ((var == 20 || var == 21) && !(pp_ok && N >= pp_min_n)) var = 14;
-    // persistent kernel with the epilogue pipelined into the next tile's k-loop: whole tiles, K a multiple of 64
-    // and >= 12 stages, plain epilogue without residual / dropout, and at least two tiles per CU
-    // (the persistent pipelined kernel: 5-6 % ahead of the 32 x 32 x 16 one-shot kernel on plain N = 2304 launches on
-    // some boxes, behind it on others, and behind the 16 x 16 x 32 one-shot kernel everywhere measured: opt-in)
-    static const int pipe_env = [] { const char* e = getenv("VY_GEMM_PIPE"); return e ? atoi(e) : 0; }();
-    // 16 x 16 x 32 MFMAs in the X-ring kernel: bit-identical outputs, 8-12 % faster on the K >= 2304 launches and the
-    // dgrads, 3-8 % on K = 768 (tools/exp_gemm.py -1 40, tools/bench_dgrad.py -1 40); VY_GEMM_M16=0: the 32 x 32 x 16 kernel
-    static const int m16_env = [] { const char* e = getenv("VY_GEMM_M16"); return e ? atoi(e) : 1; }();
-    int pipe_on = pipe_env;
-    if (var == 31) { var = 14; pipe_on = 0; }   // the default selection without the pipelined kernel (A/B runs, tests)
-    if constexpr (EPI == 0 && !GRAD) {
-      const int64_t tiles_n192 = vy_cdiv(N, 192);
-      const int64_t tiles = (M / 256) * tiles_n192;
-      // N < 3072: the layer projections.  Wider outputs keep the one-shot 256 x 256 tiles (fewer operand bytes per FLOP);
-      // the persistent kernel takes ragged widths too (var 30 / VY_GEMM_PIPE_WIDE=1 force it: on the vocabulary
-      // projection, 65 tiles per CU, it measured 2.15-2.25 ms against 1.66-1.72 ms -- tools/bench_lmhead.py)
-      static const int pipe_wide = [] { const char* e = getenv("VY_GEMM_PIPE_WIDE"); return e ? atoi(e) : 0; }();
-      const bool wide_ok = var == 30 || (pipe_wide && N >= 8192);
-      if ((var == 14 || var == 30) && pipe_on && M % 256 == 0 && (N % 192 == 0 || wide_ok) && K % 64 == 0 && K >= 768 &&
-          tiles >= 2 * 256 && !ep.residual && !ep.residual2 && !ep.drop.thr && ep.vec_ok && !ep.pre && (N < 3072 || wide_ok)) {
-        static const int pipe_knob = [] { const char* e = getenv("VY_GEMM_PIPE_KNOB"); return e ? atoi(e) : 0; }();
-        const int g = (int)(tiles < 256 ? tiles : 256);
-        hipLaunchKernelGGL((gemm_nt_bf16_pipe_kernel<ACT>), dim3(g), dim3(512), 0, st, X, ldx, W, ldw, (int)M, (int)N,
-                           (int)K, (int)tiles_n192, (int)tiles, ep, pipe_knob);
-        return 0;
-      }
-    }
-    if (var == 20 || var == 21) {   // 4-wave 256 x 192 tiles, two workgroups per CU
-      if (var == 20)
-        hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI, ACT, GRAD, 0>), dim3(tm * tn), dim3(256), 0,
-                           st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
-      else
-        hipLaunchKernelGGL((gemm_nt_bf16_pp_kernel<EPI, ACT, GRAD, 1>), dim3(tm * tn), dim3(256), 0,
-                           st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
-    } else if (var == 8 || (var < 0 && wide)) {
+    if (var == 8 || (var != 9 && var != 40 && var != 41 && !vy_m16_on() && wide)) {
       const int tn2 = (int)vy_cdiv(N, 256);
       hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
-    } else if (var == 10) {  // 4 waves, 128 x 128 per wave: fewest LDS bytes per FLOP
-      const int tn2 = (int)vy_cdiv(N, 256);
-      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(256), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
-    } else if (var == 12) {  // 128 x 192, 4 waves, 80 KiB LDS: two workgroups per CU overlap epilogue and main loop
-      const int tm2 = (int)vy_cdiv(M, 128);
-      hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm2 * tn), dim3(256), 0,
+    } else if (var == 9 || (var != 40 && var != 41 && !vy_m16_on())) {
+      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
-    } else if (var == 11) {  // 4 waves, 128 x 96 per wave
-      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 2, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(256), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
-    } else if (var == 41 || (m16_env && var == 14 && wide)) {  // 256 x 256 tiles on 16 x 16 x 32 MFMAs (FFN1 -8 %, vocabulary projection -7.5 %)
+    } else if (var == 41 || (var != 40 && wide)) {
       const int tn2 = (int)vy_cdiv(N, 256);
       hipLaunchKernelGGL((gemm_nt_bf16_m16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
-    } else if (var == 40 || (m16_env && (var == 14 && !wide))) {  // the x3 kernel on 16 x 16 x 32 MFMAs
+    } else {
       hipLaunchKernelGGL((gemm_nt_bf16_x3m16_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
                          st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
-    } else if (var == 13 || (var == 14 && !wide) || (var == 15 && !wide)) {  // X in a 3-deep ring, W in two buffers
-      hipLaunchKernelGGL((gemm_nt_bf16_x3_kernel<192, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
-    } else if (var == 15) {  // ... and the 256-wide tile for N >= 3072 in the same form (160 KiB of LDS)
-      const int tn2 = (int)vy_cdiv(N, 256);
-      hipLaunchKernelGGL((gemm_nt_bf16_x3_kernel<256, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
-    } else if (var == 14) {  // wide shapes keep the two-stage 256 x 256 kernel
-      const int tn2 = (int)vy_cdiv(N, 256);
-      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 256, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn2), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn2, ep, eq, rot);
-    } else if (var == 9 || var < 0) {
-      hipLaunchKernelGGL((gemm_nt_bf16_kernel<256, 192, 4, 2, EPI, ACT, GRAD>), dim3(tm * tn), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq, rot);
-    } else if (var == 1) {
-      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 1, 4>), dim3(tm * tn), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
-    } else if (var == 2) {
-      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 2, 4>), dim3(tm * tn), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
-    } else if (var == 5) {
-      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 0, 5>), dim3(tm * tn), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
-    } else {
-      hipLaunchKernelGGL((gemm_nt_bf16_ring_kernel<192, EPI, ACT, GRAD, 0, 4>), dim3(tm * tn), dim3(512), 0,
-                         st, X, ldx, W, ldw, (int)M, (int)N, (int)K, tn, ep, eq);
     }
   }
   return 0;
