@@ -282,12 +282,12 @@ def test_out_of_range_labels_are_ignored_and_flagged():
     loss = m.clm_loss(ids, bad)
     m.lm_head.label_error.zero_()
     want = m.clm_loss(ids, asign)
-    assert abs(float(loss) - float(want)) < 2e-5, (float(loss), float(want))      # fused (bf16, V <= 65536) path
+    assert abs(float(loss.detach()) - float(want.detach())) < 2e-5, (float(loss.detach()), float(want.detach()))      # fused (bf16, V <= 65536) path
     m32 = Vm.DecoderModel(cfg, "rope", None).to(DEV).eval()
     m32.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
     l32, w32 = m32.clm_loss(ids, bad), m32.clm_loss(ids, asign)                  # two-pass path (fp32)
-    assert abs(float(l32) - float(w32)) < 2e-5
-    assert abs(float(l32) - float(loss)) < 5e-2                                  # the two paths agree on the scale
+    assert abs(float(l32.detach()) - float(w32.detach())) < 2e-5
+    assert abs(float(l32.detach()) - float(loss.detach())) < 5e-2                                  # the two paths agree on the scale
     m.train()
     m.lm_head.label_error.zero_()
     m.clm_loss(ids, ids)
