@@ -299,9 +299,20 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
   const int w0 = blockIdx.y * rows_per_slice, w1 = min(W, w0 + rows_per_slice);
   float a = 0.f, b = 0.f;
   if (n < N) {
-    for (int w = w0 + g; w < w1; w += 4) {
-      a += ws[(int64_t)w * N + n];
-      b += ws[(int64_t)(W + w) * N + n];
+    // eight rows of both slabs requested at once (one round trip for the usual 32-row slice; a loop of dependent
+    // 4-byte loads made this 3 MB reduction an 11.8 us launch, 25 times per step), summed in row order as before
+    for (int wb = w0 + g; wb < w1; wb += 32) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int w = wb + 4 * i;
+        const int wc = w < w1 ? w : wb;
+        av[i] = ws[(int64_t)wc * N + n];
+        bv[i] = ws[(int64_t)(W + wc) * N + n];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (wb + 4 * i < w1) { a += av[i]; b += bv[i]; }
     }
   }
   red[0][g][c] = a; red[1][g][c] = b;
