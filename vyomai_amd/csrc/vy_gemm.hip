@@ -1109,7 +1109,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_m16_splitk_kernel
   constexpr int GX = PX / NW, GW = PW / NW;
   static_assert(GX * NW == PX && GW * NW == PW, "pieces must divide over the waves");
   constexpr int STAGE = (BM + BN) * ROWB;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  // a slice is 2-16 stages, each a full L2 / MALL round trip: where three stages fit in the CU's 160 KiB (the 256-row
+  // all-rows tile: 3 x 48 KiB) two of them stay in flight behind the one being multiplied (counted vmcnt), so a short slice
+  // is ONE round trip deep instead of one per stage; the other tiles keep two buffers (one stage ahead)
+  constexpr int NBUF = (3 * STAGE <= 160 * 1024 && BM * BN > 128 * 128) ? 3 : 2;
+  constexpr int PIECES = GX + GW;   // LDS-DMA instructions per wave and stage
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1197,15 +1202,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_m16_splitk_kernel
   };
 
   if (kt0 < kt1) {   // (workgroup-uniform; an empty slice stores zeros)
+    const int n = kt1 - kt0;
     stage(kt0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(wa[0], xa[0], wf[0], xf[0]);
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int cur = (kt - kt0) & 1;
-      if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
-      const unsigned boff = cur * STAGE;
+    if (NBUF >= 3 && n > 1) stage(kt0 + 1, 1);
+    for (int i = 0; i < n; ++i) {
+      // stage i has landed for this wave (the younger stage, if any, may still be in flight) ...
+      if (NBUF >= 3 && i + 1 < n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // ... and for every wave once the barrier is passed; every wave has also finished reading the buffer of stage i - 1,
+      // which the next request overwrites
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (i + NBUF - 1 < n) stage(kt0 + i + NBUF - 1, (i + NBUF - 1) % NBUF);
+      const unsigned boff = (unsigned)(i % NBUF) * STAGE;
+      read_frags(wa[0] + boff, xa[0] + boff, wf[0], xf[0]);
       read_frags(wa[1] + boff, xa[1] + boff, wf[1], xf[1]);
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
       tie_frags(wf[0], xf[0]);
@@ -1213,10 +1223,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_nt_bf16_m16_splitk_kernel
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       tie_frags(wf[1], xf[1]);
       mma(wf[1], xf[1]);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (kt + 1 < kt1) read_frags(wa[0] + (STAGE - boff), xa[0] + (STAGE - boff), wf[0], xf[0]);
     }
   }
   // the accumulators as they sit in the registers: [slice][tile][wave][i][j][lane] f32x4
