@@ -532,7 +532,12 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* 
     Chunk<T>::load(dy + m * lddy + c, a);
     Chunk<T>::load(pre + m * ldpre + c, b);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] = a[e] * vy_act_grad<ACT>(b[e]);
+    for (int e = 0; e < VEC; ++e) {
+      // bf16: the derivative the GEMM epilogues use (vy_act_grad_fast: its error is below bf16 rounding; libm's erff made
+      // this 75 MB pass a 94 us launch); fp32 keeps the exact form (the 1e-5 parity path)
+      if constexpr (sizeof(T) == 2) o[e] = a[e] * vy_act_grad_fast<ACT>(b[e]);
+      else o[e] = a[e] * vy_act_grad<ACT>(b[e]);
+    }
     Chunk<T>::store(dx + m * lddx + c, o);
   }
 }
