@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, int row_bytes) {
 // and one raw s_barrier.
 // NS == 0 selects the asymmetric ring: the dY tile three deep, the X tile two deep (3*ATILE + 2*BTILE =
 // 80 KiB at 128 x 128 x 64: still two workgroups per CU) -- the dY loads of stage s+2 stay in flight
-// across the barrier that ends stage s, as X does in gemm_nt_bf16_x3_kernel.
+// across the barrier that ends stage s, as X does in gemm_nt_bf16_x3m16_kernel (vy_gemm.hip).
 // MF16: mfma_f32_16x16x32_bf16 instead of 32x32x16 (as in the forward / dgrad GEMMs: fewer cycles per stage and a higher
 // clock, vy_gemm.hip): 4 x WKT/16 blocks of 16 x 16 per wave, 32 rows of m per MFMA.  The transposing reads of a 16-lane
 // group take the 4 rows 4 (lane >> 4) + q (and + 16), so the two groups of a 32-lane half read DIFFERENT rows of the same
