@@ -1,7 +1,13 @@
 // GEMM family for the projection / feed-forward path:  Y[M,N] = epi(X[M,K] . W[N,K]^T)
 //
-// bf16 kernel (the product path): MFMA 32x32x16, fp32 accumulate, LDS-DMA staging.
-//   * workgroup = 4 waves; tile BM x BN x 64 (default 128 x 128), double-buffered LDS;
+// bf16 kernels (the product path): MFMA, fp32 accumulate, LDS-DMA staging, by size of M:
+//   * M > ~2304 (training, prefill): 256 x 192 tiles with the X operand in a three-deep ring (gemm_nt_bf16_x3m16_kernel) or
+//     256 x 256 two-stage tiles where N >= 3072 (gemm_nt_bf16_m16_kernel), both on mfma_f32_16x16x32_bf16, 8 waves, one
+//     workgroup per CU; gemm_nt_bf16_kernel is the same tile family on mfma_f32_32x32x16_bf16 (A/B knob, 32 x 128 fallback);
+//   * 32 < M <= ~2304: 128 x 128 tiles (two workgroups per CU) or ONE all-rows tile of 256 / 320 x 128 for 128 < M <= 320,
+//     split over K when the tile grid leaves CUs idle (gemm_nt_bf16_m16_splitk_kernel + gemm_splitk_finish_kernel);
+//   * M <= 32 (decode): weight-streaming kernels without LDS staging (gemm_skinny*), M <= 4: one wave per output column
+//     (gemv_bf16_kernel); the decode driver's straight-line versions are in vy_decode.hip;
 //   * both operands are K-contiguous ("NT"), so both MFMA fragments are 16-byte row reads
 //     (ds_read_b128) from a [rows][64] bf16 LDS image; the image is XOR-swizzled on the 16-B
 //     chunk index with (row>>1)&7, applied on the *source address* of the
