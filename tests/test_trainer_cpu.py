@@ -341,3 +341,24 @@ def test_zero_grad_after_an_unstepped_backward_starts_a_fresh_window():
     assert tr.arena.grad.abs().sum() == 0 and tr._micro == 0
     tr.train_step(lambda: model(x).pow(2).mean())          # a complete step, no complaint about a second backward
     assert tr.step_count == 1
+
+
+def test_arena_parameters_start_on_128_byte_lines_of_the_bf16_copy():
+    """Every parameter (except the followers inside a packed q/k/v group, which must stay adjacent) starts at a multiple of 64
+    elements: the odd-sized vocabulary bias used to push the LM head's matrices half a cache line off."""
+    import vyomai_amd as V
+    from vyomai_amd.training import FlatArena, LINE, _ordered_params
+    cfg = cases.micro_cfg()
+    cfg.vocab_size = 1031                     # odd, like 50265
+    m = V.DecoderModel(cfg, "rope", "gqa")
+    arena = FlatArena(m, shadow_dtype=torch.bfloat16)
+    followers = _ordered_params.followers
+    names = {id(p): n for n, p in arena.items}
+    assert any("lm_head.decoder.weight" in n for n in names.values())
+    for p, o in zip(arena.params, arena.offsets):
+        if id(p) not in followers:
+            assert o % LINE == 0, (names[id(p)], o)
+    att = m.all_layer[0].attention
+    w, b = att._packed()                       # the packed views still cover the three members without gaps
+    assert w.shape[0] == att.query.weight.shape[0] + att.key.weight.shape[0] + att.value.weight.shape[0]
+    assert att.key.weight.data_ptr() == att.query.weight.data_ptr() + att.query.weight.numel() * 4

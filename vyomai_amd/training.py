@@ -32,6 +32,12 @@ import torch.distributed as dist
 import torch.nn as nn
 
 ALIGN = 8  # elements: keeps every bf16 parameter 16-byte aligned inside the shadow arena
+# ... and every parameter that is not a follower inside a packed q/k/v group STARTS on a 128-byte line of the bf16 arena
+# (64 elements).  The vocabulary bias (50265 elements) used to leave everything registered after it -- the LM head's
+# projections -- 64 bytes off a line: every 1536-byte weight row then straddled 13 lines instead of 12 and each 128-byte
+# row segment an LDS-DMA instruction fetches came from two lines (the decode step's vocabulary projection: 28.8 us inside
+# bench.py against 18.5 us on line-aligned weights, profiles/r03_*).
+LINE = int(os.environ.get("VY_ARENA_LINE", "64"))   # (8: the round-2 layout, for A/B runs)
 
 
 def _ordered_params(model: nn.Module) -> List[Tuple[str, nn.Parameter]]:
@@ -44,6 +50,7 @@ def _ordered_params(model: nn.Module) -> List[Tuple[str, nn.Parameter]]:
     by_id = {id(p): n for n, p in named}
     taken = set()
     out: List[Tuple[str, nn.Parameter]] = []
+    followers: set = set()       # ids of packed-group members behind the first: they must follow it without a gap
     groups: Dict[int, List[nn.Parameter]] = {}
     for mod in model.modules():
         if isinstance(mod, _SelfAttentionBase) and not mod._fused_qkv:
@@ -53,12 +60,15 @@ def _ordered_params(model: nn.Module) -> List[Tuple[str, nn.Parameter]]:
         if id(p) in taken:
             continue
         if id(p) in groups:
-            for m in groups[id(p)]:
+            for j, m in enumerate(groups[id(p)]):
                 out.append((by_id[id(m)], m))
                 taken.add(id(m))
+                if j:
+                    followers.add(id(m))
         else:
             out.append((n, p))
             taken.add(id(p))
+    _ordered_params.followers = followers
     return out
 
 
@@ -72,7 +82,10 @@ class FlatArena:
         device = params[0].device
         self.offsets: List[int] = []
         off = 0
+        followers = getattr(_ordered_params, "followers", set())
         for p in params:
+            if id(p) not in followers:
+                off = (off + LINE - 1) // LINE * LINE
             self.offsets.append(off)
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
