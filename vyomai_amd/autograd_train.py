@@ -92,12 +92,24 @@ def _wt_cached(owner, key_fn, src_fn) -> torch.Tensor:
             owner._vy_wt_key = key
         return view
     N, K = src.shape
-    ld = (N + 7) // 8 * 8
+    ld = _row_stride(N)
     view = torch.zeros((K, ld), dtype=src.dtype, device=src.device)[:, :N]  # pad columns stay zero
     ops.transpose(src, view)
     owner._vy_wt_view, owner._vy_wt_key = view, key
     owner._vy_wt_entry = _WT.register(owner, key_fn, src_fn, view)
     return view
+
+
+_ROW_GRANULE = int(os.environ.get("VY_ROW_GRANULE", "64"))   # (8: the layout of rounds 1-2, for A/B runs)
+
+
+def _row_stride(n: int) -> int:
+    """Row stride (elements) of a matrix with n columns that a GEMM reads as an operand: whole 128-byte lines per row
+    (64 bf16), so that no row starts in the middle of a line.  With the 16-byte granule of rounds 1-2 the 50265-wide logits had a
+    100,544-byte stride: every second row of the dgrad / wgrad operand began 64 bytes into a line and each 128-byte piece an
+    LDS-DMA instruction fetches came from two lines."""
+    g = _ROW_GRANULE
+    return (n + g - 1) // g * g
 
 
 def _wt(param: torch.Tensor, dtype) -> torch.Tensor:
@@ -544,7 +556,7 @@ class LMHeadFn(torch.autograd.Function):
         ops.linear(hidden, _shadow(wd, dt), _shadow(bd, dt), act=ACT_GELU_ERF, pre_out=pre, out=g)
         n, mean, rstd = ops.layernorm(g, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
         V = wv.shape[0]
-        ld = (V + 7) // 8 * 8
+        ld = _row_stride(V)
         buf = torch.zeros((*hidden.shape[:-1], ld), dtype=dt, device=hidden.device)
         logits = buf[..., :V]
         ops.linear(n, _shadow(wv, dt), _shadow(bias, dt), out=logits)
@@ -600,7 +612,7 @@ class LMHeadLossFn(torch.autograd.Function):
         ops.linear(hidden, _shadow(wd, dt), _shadow(bd, dt), act=ACT_GELU_ERF, pre_out=pre, out=g)
         n, mean, rstd = ops.layernorm(g, _shadow(ln_w, dt), _shadow(ln_b, dt), eps, save_stats=True)
         V = wv.shape[0]
-        ld = (V + 7) // 8 * 8
+        ld = _row_stride(V)
         buf = torch.empty((B * L, ld), dtype=dt, device=dev)
         if ld != V:
             buf[:, V:].zero_()  # only the pad columns: the GEMM writes the rest
